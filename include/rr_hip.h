@@ -1,0 +1,320 @@
+/*
+ * rr_hip.h — C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * This is the drop-in boundary for the reference's render seam
+ *     pub fn render_multi(scene, lights, cam, background, max_depth,
+ *                         samples_per_pixel, img_width, img_height)
+ *         -> ImageBuffer<Rgb<u8>>                       (src/render.rs:128)
+ * The reference has no FFI of its own; a host (Rust, C++ or Python) flattens
+ * its scene tree into the plain arrays below, uploads them once, and calls
+ * rr_render / rr_render_device instead of render_multi.
+ *
+ * Conventions: every function returns 0 on success or a negative RR_E_* code;
+ * rr_last_error() returns a thread-local message for the last failure.  No
+ * exceptions cross the boundary.  The caller owns every host pointer it passes
+ * in; the library owns the device memory behind a context.  A context belongs
+ * to ONE device and is used from one thread at a time (one process per GPU).
+ * All arithmetic on the path is IEEE f32 (src/vec3.rs:8-12).
+ */
+#ifndef RR_HIP_H
+#define RR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- errors */
+#define RR_OK 0
+#define RR_E_INVALID -1   /* bad argument / malformed scene               */
+#define RR_E_NO_DEVICE -2 /* no usable gfx950 device                      */
+#define RR_E_HIP -3       /* a HIP runtime call failed                    */
+#define RR_E_NO_SCENE -4  /* render/primary-hit call before scene upload  */
+#define RR_E_LIMIT -5     /* a size exceeds what the device layout holds  */
+
+/* ------------------------------------------------- geometry references */
+/* A "ref" names one record of the flattened Geometry tree
+ * (enum GeometryType, src/collider.rs:34-47): tag in bits 31..28, index into
+ * that tag's array in bits 27..0.                                          */
+#define RR_TAG_SPHERE 0u        /* GeometryType::Sphere                    */
+#define RR_TAG_MOVING_SPHERE 1u /* GeometryType::MovingSphere              */
+#define RR_TAG_RECT 2u          /* XYRect / XZRect / YZRect (axis in record) */
+#define RR_TAG_TRIANGLE 3u      /* GeometryType::Triangle                  */
+#define RR_TAG_CUBOID 4u        /* GeometryType::Cuboid (6 rects)          */
+#define RR_TAG_MEDIUM 5u        /* GeometryType::ConstantMedium            */
+#define RR_TAG_INSTANCE 6u      /* TranslateInstance / YRotationInstance   */
+#define RR_TAG_BVH 7u           /* GeometryType::BVHNode                   */
+#define RR_TAG_LIST 8u          /* ColliderList and SceneColliders.objects */
+#define RR_TAG_COUNT 9u
+#define RR_REF(tag, index) ((((uint32_t)(tag)) << 28) | ((uint32_t)(index)))
+#define RR_REF_TAG(ref) (((uint32_t)(ref)) >> 28)
+#define RR_REF_INDEX(ref) (((uint32_t)(ref)) & 0x0FFFFFFFu)
+#define RR_REF_NONE 0xFFFFFFFFu
+
+/* Rect axis: which plane the rect lies in.
+ *   RR_RECT_XY: a = x, b = y, k = z, normal (0,0,1)  (collider.rs:344-359)
+ *   RR_RECT_XZ: a = x, b = z, k = y, normal (0,1,0)  (collider.rs:367-382)
+ *   RR_RECT_YZ: a = y, b = z, k = x, normal (1,0,0)  (collider.rs:405-420)  */
+#define RR_RECT_XY 0u
+#define RR_RECT_XZ 1u
+#define RR_RECT_YZ 2u
+
+/* Instance kinds (collider.rs:480-528). */
+#define RR_INST_TRANSLATE 0u
+#define RR_INST_ROTATE_X 1u
+#define RR_INST_ROTATE_Y 2u
+#define RR_INST_ROTATE_Z 3u
+
+/* Material kinds (enum MaterialType, src/material.rs:43-49). */
+#define RR_MAT_LAMBERTIAN 0u
+#define RR_MAT_GLOSSY 1u
+#define RR_MAT_DIELECTRIC 2u
+#define RR_MAT_ISOTROPIC 3u
+#define RR_MAT_EMISSIVE 4u
+
+/* Texture kinds (enum TextureType, src/texture.rs:28-33). */
+#define RR_TEX_SOLID 0u
+#define RR_TEX_CHECKERED 1u
+#define RR_TEX_NOISE 2u
+#define RR_TEX_IMAGE 3u
+
+/* ------------------------------------------------------- scene records */
+/* prim_id is the caller's stable primitive number (depth-first order of the
+ * Geometry tree); the library only echoes it in rr_hit.                     */
+
+typedef struct rr_sphere { /* collider.rs:35,278-301 */
+    float center[3];
+    float radius; /* may be negative (hollow-bubble trick, main.rs:44) */
+    uint32_t material;
+    uint32_t prim_id;
+} rr_sphere;
+
+typedef struct rr_moving_sphere { /* collider.rs:36,269-271,309-331 */
+    float center0[3];
+    float center1[3];
+    float time0, time1;
+    float radius;
+    uint32_t material;
+    uint32_t prim_id;
+} rr_moving_sphere;
+
+typedef struct rr_rect { /* collider.rs:37-39 */
+    float a0, a1, b0, b1, k;
+    uint32_t axis; /* RR_RECT_* */
+    uint32_t material;
+    uint32_t prim_id;
+} rr_rect;
+
+typedef struct rr_triangle { /* collider.rs:46,219-226,627-667 */
+    float p0[3], p1[3], p2[3];
+    float normal[3]; /* normalize(cross(p1-p0, p2-p0)), precomputed by the host */
+    uint32_t material;
+    uint32_t prim_id;
+} rr_triangle;
+
+typedef struct rr_cuboid { /* collider.rs:40,86-101,428-430 */
+    uint32_t first_rect; /* 6 consecutive rr_rect records, constructor order */
+} rr_cuboid;
+
+typedef struct rr_medium { /* collider.rs:41,102-107,435-475 */
+    uint32_t boundary;     /* ref */
+    float neg_inv_density; /* -1/density */
+    uint32_t material;     /* isotropic */
+    uint32_t prim_id;
+} rr_medium;
+
+typedef struct rr_instance { /* collider.rs:42-43,480-528 */
+    uint32_t kind;  /* RR_INST_* */
+    uint32_t child; /* ref */
+    float v[3];     /* translate: displacement; rotate: v[0]=sin, v[1]=cos */
+} rr_instance;
+
+typedef struct rr_bvh_node { /* collider.rs:44,536-581 */
+    float bmin[3], bmax[3];
+    uint32_t left, right; /* refs */
+    uint32_t axis;        /* 0..2, indexes ray.direction for child order */
+    uint32_t has_box;     /* 0: Option<AABB> is None → no box test */
+} rr_bvh_node;
+
+typedef struct rr_list { /* collider.rs:45,586-607,751-772 */
+    uint32_t first_child; /* index into rr_flat_scene.child_refs */
+    uint32_t n_children;
+} rr_list;
+
+typedef struct rr_material { /* material.rs:43-82 */
+    uint32_t type;    /* RR_MAT_* */
+    uint32_t texture; /* lambertian / isotropic / emissive */
+    float color[3];   /* glossy albedo */
+    float param;      /* glossy fuzz (already clamped to ≤1) or dielectric index */
+} rr_material;
+
+typedef struct rr_texture { /* texture.rs:28-103 */
+    uint32_t type;   /* RR_TEX_* */
+    float color0[3]; /* solid colour / checker odd colour  */
+    float color1[3]; /* checker even colour                */
+    uint32_t index;  /* noise: Perlin table; image: image  */
+    float scale;     /* noise */
+    uint32_t depth;  /* noise turbulence octaves */
+} rr_texture;
+
+#define RR_PERLIN_POINTS 256
+typedef struct rr_perlin { /* perlin.rs:5-11 */
+    float ranvec[RR_PERLIN_POINTS][3];
+    uint8_t perm_x[RR_PERLIN_POINTS];
+    uint8_t perm_y[RR_PERLIN_POINTS];
+    uint8_t perm_z[RR_PERLIN_POINTS];
+} rr_perlin;
+
+typedef struct rr_image { /* texture.rs:9-23: decoded to RGB8 by the host */
+    uint32_t width, height;
+    uint64_t offset; /* byte offset of texel (0,0) in rr_flat_scene.image_bytes; rows top-down, 3 B/texel */
+} rr_image;
+
+typedef struct rr_light { /* the `lights: Geometry` argument, collider.rs:714-725 */
+    uint32_t is_xzrect; /* 0: any other geometry → pdf 0, direction (1,0,0) */
+    float x0, x1, z0, z1, k;
+} rr_light;
+
+typedef struct rr_camera { /* the fields get_ray reads, camera.rs:76-84 */
+    float origin[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+    float shutter_open, shutter_close;
+} rr_camera;
+
+typedef struct rr_flat_scene {
+    uint32_t n_spheres;        const rr_sphere* spheres;
+    uint32_t n_moving_spheres; const rr_moving_sphere* moving_spheres;
+    uint32_t n_rects;          const rr_rect* rects;
+    uint32_t n_triangles;      const rr_triangle* triangles;
+    uint32_t n_cuboids;        const rr_cuboid* cuboids;
+    uint32_t n_media;          const rr_medium* media;
+    uint32_t n_instances;      const rr_instance* instances;
+    uint32_t n_bvh_nodes;      const rr_bvh_node* bvh_nodes;
+    uint32_t n_lists;          const rr_list* lists;
+    uint32_t n_child_refs;     const uint32_t* child_refs;
+    uint32_t n_materials;      const rr_material* materials;
+    uint32_t n_textures;       const rr_texture* textures;
+    uint32_t n_perlin;         const rr_perlin* perlin;
+    uint32_t n_images;         const rr_image* images;
+    uint64_t n_image_bytes;    const uint8_t* image_bytes;
+    uint32_t root;             /* ref of the list that is SceneColliders.objects */
+    rr_light light;
+    rr_camera camera;
+    float background[3];
+} rr_flat_scene;
+
+/* ---------------------------------------------------------- rendering */
+typedef struct rr_render_params {
+    uint32_t width, height;
+    uint32_t samples_per_pixel; /* as passed to render_multi                           */
+    uint32_t n_slices;          /* K = the reference's n_threads (render.rs:129); each slice
+                                   renders samples_per_pixel / K samples (render.rs:130)  */
+    uint32_t slice_begin, slice_end; /* this call renders slices [begin,end) ⊂ [0,K)   */
+    uint32_t max_depth;
+    uint64_t seed;
+    uint32_t sample_offset;     /* added to the per-pixel sample number in the RNG key:
+                                   gives each GPU of a weak-scaling job its own samples   */
+    uint32_t flags;             /* RR_FLAG_* */
+} rr_render_params;
+
+#define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests (slower build of the kernel) */
+
+typedef struct rr_counters {
+    uint64_t samples;     /* camera rays started                                         */
+    uint64_t rays;        /* ray_color invocations with depth > 0 (one scene.intersect each) */
+    uint64_t box_tests;   /* AABB::intersect calls                (RR_FLAG_COUNTERS)      */
+    uint64_t prim_tests;  /* sphere/rect/triangle intersector calls (RR_FLAG_COUNTERS)    */
+    uint64_t inst_visits; /* instance + medium visits              (RR_FLAG_COUNTERS)     */
+    uint64_t reserved[3];
+} rr_counters;
+
+typedef struct rr_hit {
+    int32_t prim_id;   /* -1 = miss */
+    uint32_t material;
+    float t;
+    float point[3];
+    float normal[3];
+    float u, v;
+    uint32_t front_face;
+} rr_hit;
+
+typedef struct rr_scene_info {
+    uint32_t stack_words;    /* per-lane traversal stack the scene needs */
+    uint32_t max_inst_depth; /* deepest instance nesting                 */
+    uint64_t device_bytes;   /* bytes of scene data resident in HBM      */
+    uint32_t n_prims;        /* spheres + moving spheres + rects + triangles */
+    uint32_t reserved;
+} rr_scene_info;
+
+typedef struct rr_context rr_context;
+
+/* Number of visible HIP devices (0 on a host without a GPU; not an error). */
+int rr_device_count(int* count);
+
+/* Create / destroy the per-device context.  Fails with RR_E_NO_DEVICE when
+ * `device` is not a visible gfx950 GPU: there is no CPU fallback.           */
+int rr_context_create(int device, rr_context** out);
+int rr_context_destroy(rr_context* ctx);
+
+/* Validate (every ref in range, tree-shaped, bounded depth), pack and copy the
+ * scene into HBM.  Replaces the scene, lights, cam and background arguments
+ * of render_multi (render.rs:128).  A later call replaces the scene.        */
+int rr_scene_upload(rr_context* ctx, const rr_flat_scene* scene);
+int rr_scene_info_get(rr_context* ctx, rr_scene_info* out);
+
+/* Closest-hit records for caller-supplied rays, exactly as
+ * SceneColliders::intersect(r, t_min, t_max) returns them (collider.rs:751).
+ * rays: n × 7 f32 (origin xyz, direction xyz, time), host memory.
+ * Constant media draw from the counter RNG keyed by (seed, ray index).      */
+int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min, float t_max,
+                    uint64_t seed, rr_hit* out_hits);
+
+/* Render slices [slice_begin, slice_end) of the image; replaces the parallel
+ * loop of render_multi (render.rs:135-151) and render_worker (render.rs:89-124).
+ * All output pointers are DEVICE pointers owned by the caller, any of the
+ * optional ones may be NULL:
+ *   d_slice_sums : (slice_end-slice_begin) × H × W × 3 f32, the per-slice pixel sums
+ *                  (pixel_color of render.rs:93-100, NaN kept), row 0 = top.  Required.
+ *   d_resolved   : H × W × 3 f32, Σ over the rendered slices of the per-slice
+ *                  tonemapped value of render.rs:102-119 (what the mutex sum
+ *                  of render.rs:141-150 adds up).                  Optional.
+ *   d_linear     : H × W × 3 f32, Σ over the rendered slices of the NaN-scrubbed
+ *                  pixel sums (linear radiance × samples).          Optional.
+ *   d_counters   : one rr_counters, ADDED to (caller zeroes it).   Optional.
+ * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream) and the
+ * call returns without synchronising.                                       */
+int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
+                     void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
+
+/* Convenience wrapper for hosts without their own device buffers: allocates,
+ * renders all of [slice_begin,slice_end), synchronises and copies to HOST
+ * buffers.  out_rgb8 (H×W×3 u8) is the saturating `as u8` cast of render.rs:156-159
+ * and is only the final image when the call covers all K slices; out_slice_sums
+ * has the layout of d_slice_sums.  Any output may be NULL.                                                             */
+int rr_render(rr_context* ctx, const rr_render_params* params, uint8_t* out_rgb8,
+              float* out_resolved, float* out_linear, float* out_slice_sums,
+              rr_counters* out_counters);
+
+/* f32 → u8 cast of the summed slice images (render.rs:156-159) on the device:
+ * d_rgb8[i] = saturating truncation of d_resolved[i], NaN → 0.              */
+int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uint64_t n,
+                      void* hip_stream);
+
+/* Milliseconds the dominant (path-tracing) kernel of the last rr_render_device /
+ * rr_render call took, measured with HIP events on the stream it ran on.
+ * Synchronises with that kernel.                                            */
+int rr_last_kernel_ms(rr_context* ctx, float* ms);
+
+const char* rr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RR_HIP_H */

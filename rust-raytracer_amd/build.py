@@ -1,0 +1,65 @@
+"""In-tree builds: librr_hip.so (hipcc, gfx950), librr_host.so (g++), oracle/librr_oracle.so (make).
+
+hipcc cross-compiles without a GPU, so all three build on a CPU-only box.  A library is
+rebuilt when it is older than any of its sources.
+"""
+import os
+import subprocess
+
+from . import abi
+
+CSRC = os.path.join(abi.PKG_DIR, "csrc")
+HOST = os.path.join(abi.PKG_DIR, "host")
+INCLUDE = os.path.join(abi.REPO_DIR, "include")
+
+# -ffp-contract=off: the path's arithmetic contract is one IEEE f32 operation per source
+# operation, as in the reference's Rust (no fused multiply-add), so that ids, t and normals
+# agree with the CPU oracle bit for bit.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+GXX_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+
+def _headers():
+    return [os.path.join(INCLUDE, "rr_hip.h"), os.path.join(INCLUDE, "rr_host.h")]
+
+
+def build_hip(force=False):
+    src = [os.path.join(CSRC, "rr_hip.hip")]
+    deps = src + [os.path.join(CSRC, "rr_device.h")] + _headers()
+    if force or _stale(abi.HIP_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIPCC_FLAGS + ["-o", abi.HIP_LIB] + src)
+    return abi.HIP_LIB
+
+
+def build_host(force=False):
+    src = [os.path.join(HOST, f) for f in ("scene.cpp", "flatten.cpp", "scenes.cpp", "host_capi.cpp")]
+    deps = src + [os.path.join(HOST, "scene.hpp")] + _headers()
+    if force or _stale(abi.HOST_LIB, deps):
+        _run([os.environ.get("CXX", "g++")] + GXX_FLAGS + ["-o", abi.HOST_LIB] + src)
+    return abi.HOST_LIB
+
+
+def build_oracle(force=False):
+    d = os.path.join(abi.REPO_DIR, "oracle")
+    if force:
+        _run(["make", "-C", d, "clean"])
+    _run(["make", "-C", d])
+    return os.path.join(d, "librr_oracle.so")
+
+
+def build_all(force=False):
+    return [build_hip(force), build_host(force), build_oracle(force)]

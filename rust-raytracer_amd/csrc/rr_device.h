@@ -1,0 +1,870 @@
+// Device-side scene layout and the gfx950 path-tracing code (traversal machine,
+// hit reconstruction, shading, camera, RNG).  Included only by rr_hip.hip.
+//
+// Arithmetic contract: every f32 operation below is a single IEEE operation in the
+// order the reference's Rust evaluates it (build with -ffp-contract=off; hipcc's
+// default correctly-rounded f32 divide and sqrt).  Transcendentals (sin, cos, acos,
+// atan2, log10) come from the device math library and may differ from a host libm
+// in the last bits.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rr_hip.h"
+
+namespace rrdev {
+
+// ------------------------------------------------------------ packed refs
+// Device refs: index in bits 25..0, tag in bits 29..26, two spare bits 31..30.
+// In a BVH node the spare bits of `left` hold the split axis and bit 30 of `right`
+// holds has_box, so a node is exactly two 16-byte loads.
+constexpr uint32_t IDX_BITS = 26;
+constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t dref(uint32_t tag, uint32_t idx, uint32_t extra = 0) {
+    return idx | (tag << IDX_BITS) | (extra << 30);
+}
+__host__ __device__ inline uint32_t dtag(uint32_t r) { return (r >> IDX_BITS) & 15u; }
+__host__ __device__ inline uint32_t didx(uint32_t r) { return r & IDX_MASK; }
+__host__ __device__ inline uint32_t dextra(uint32_t r) { return r >> 30; }
+
+constexpr uint32_t MAX_CHAIN = 8;  // deepest instance nesting the device layout holds
+
+// Stack frame headers: kind in bits 31..28, record index below.
+constexpr uint32_t F_LIST = 1u << 28, F_BVH = 2u << 28, F_INST = 3u << 28, F_MED1 = 4u << 28, F_MED2 = 5u << 28;
+constexpr uint32_t F_KIND = 0xF0000000u;
+constexpr uint32_t FRAME_WORDS_LIST = 2, FRAME_WORDS_BVH = 2, FRAME_WORDS_INST = 1, FRAME_WORDS_MEDIUM = 5;
+
+struct DevMaterial {  // 32 B
+    uint32_t type, texture;
+    float r, g, b, param;
+    uint32_t pad0, pad1;
+};
+struct DevTexture {  // 48 B
+    uint32_t type, index, depth, pad;
+    float c0[3], scale;
+    float c1[3], pad2;
+};
+struct DevImage {
+    uint32_t width, height;
+    uint64_t offset;
+};
+
+struct DevScene {
+    const float4* bvh;          // 2 per node: (min.xyz, left), (max.xyz, right)
+    const float4* sphere;       // (center.xyz, radius)
+    const uint2* sphere_meta;   // (material, owner instance)
+    const float4* msphere;      // 3 per record: (c0.xyz, time0), (c1.xyz, time1), (radius, material, owner, -)
+    const float4* rect;         // 2 per record: (a0, a1, b0, b1), (k, axis, material, owner)
+    const float4* tri;          // 3 per record: p0.xyz p1.x | p1.yz p2.xy | p2.z n.xyz
+    const uint2* tri_meta;      // (material, owner instance)
+    const uint32_t* cuboid;     // first rect
+    const uint4* medium;        // (boundary, neg_inv_density bits, material, owner instance)
+    const float4* inst;         // 2 per record: (kind, child, v0, v1), (v2, depth, -, -)
+    const uint32_t* inst_chain; // MAX_CHAIN per instance: enclosing instances, outermost first, itself last
+    const uint2* list;          // (first child, n children)
+    const uint32_t* child_refs;
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const float* perlin_vec;      // 256*3 per table
+    const uint8_t* perlin_perm;   // 3*256 per table
+    const DevImage* images;
+    const uint8_t* image_bytes;
+    uint32_t root;  // device ref of the top-level list
+    uint32_t light_is_xzrect;
+    float light_x0, light_x1, light_z0, light_z1, light_k;
+    rr_camera cam;
+    float background[3];
+};
+
+struct Counts {
+    uint32_t rays, box_tests, prim_tests, inst_visits, samples;
+};
+
+// ------------------------------------------------------------------ math
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ float len3(f3 a) { return sqrtf(len2(a)); }
+__device__ __forceinline__ f3 unit3(f3 a) { return a / len3(a); }
+__device__ __forceinline__ f3 neg3(f3 a) { return a * -1.0f; }
+__device__ __forceinline__ float comp(f3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTau = 6.28318530717958647692f;
+constexpr float kF32Max = 3.40282347e+38f;
+
+// ------------------------------------------------------------------- rng
+// Philox4x32-10 stream keyed by (seed; pixel, sample, bounce); draw n is word n&3 of
+// block n>>2; u32 → f32 on the 2^-23 grid of [0,1).
+struct Rng {
+    uint32_t k0, k1, c0, c1, c2, n;
+    uint32_t b0, b1, b2, b3;
+    __device__ __forceinline__ void start(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce) {
+        k0 = static_cast<uint32_t>(seed);
+        k1 = static_cast<uint32_t>(seed >> 32);
+        c0 = pixel;
+        c1 = sample;
+        c2 = bounce;
+        n = 0;
+    }
+    __device__ __forceinline__ void refill() {
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = n >> 2, ka = k0, kb = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
+            uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+            uint32_t y0 = hi1 ^ x1 ^ ka, y2 = hi0 ^ x3 ^ kb;
+            x0 = y0;
+            x1 = lo1;
+            x2 = y2;
+            x3 = lo0;
+            ka += 0x9E3779B9u;
+            kb += 0xBB67AE85u;
+        }
+        b0 = x0;
+        b1 = x1;
+        b2 = x2;
+        b3 = x3;
+    }
+    __device__ __forceinline__ uint32_t next_u32() {
+        uint32_t w = n & 3u;
+        if (w == 0) refill();
+        ++n;
+        return w == 0 ? b0 : (w == 1 ? b1 : (w == 2 ? b2 : b3));
+    }
+    __device__ __forceinline__ float random() { return static_cast<float>(next_u32() >> 9) * (1.0f / 8388608.0f); }
+    __device__ __forceinline__ float randrange(float lo, float hi) {
+        for (;;) {
+            float v = random() * (hi - lo) + lo;
+            if (v < hi) return v;
+        }
+    }
+};
+// Advance past draws whose values nobody reads.  next_u32 only refills when n&3 == 0,
+// so a skip that lands inside a block that is not the buffered one refills here.
+__device__ __forceinline__ void rng_skip(Rng& g, uint32_t count) {
+    uint32_t before = g.n >> 2;
+    bool had_block = (g.n & 3u) != 0;  // current block is buffered only if partially consumed
+    g.n += count;
+    uint32_t after = g.n >> 2;
+    if ((g.n & 3u) != 0 && (after != before || !had_block)) g.refill();
+}
+
+constexpr uint32_t CAMERA_BOUNCE = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------- instances
+// Ray into the space of instance ii (collider.rs:481 translate, 499-509 rotate).
+__device__ __forceinline__ void inst_apply_ray(const DevScene& sc, uint32_t ii, f3& o, f3& d) {
+    const float4 a = sc.inst[2 * ii];
+    const uint32_t kind = __float_as_uint(a.x);
+    if (kind == RR_INST_TRANSLATE) {
+        const float v2 = sc.inst[2 * ii + 1].x;
+        o = o - mk3(a.z, a.w, v2);
+        return;
+    }
+    const float s = a.z, c = a.w;
+    if (kind == RR_INST_ROTATE_Y) {  // others = (X, Z)
+        f3 no = o, nd = d;
+        no.x = c * o.x - s * o.z;
+        no.z = s * o.x + c * o.z;
+        nd.x = c * d.x - s * d.z;
+        nd.z = s * d.x + c * d.z;
+        o = no;
+        d = nd;
+    } else if (kind == RR_INST_ROTATE_X) {  // others = (Y, Z)
+        f3 no = o, nd = d;
+        no.y = c * o.y - s * o.z;
+        no.z = s * o.y + c * o.z;
+        nd.y = c * d.y - s * d.z;
+        nd.z = s * d.y + c * d.z;
+        o = no;
+        d = nd;
+    } else {  // ROTATE_Z, others = (X, Y)
+        f3 no = o, nd = d;
+        no.x = c * o.x - s * o.y;
+        no.y = s * o.x + c * o.y;
+        nd.x = c * d.x - s * d.y;
+        nd.y = s * d.x + c * d.y;
+        o = no;
+        d = nd;
+    }
+}
+__device__ __forceinline__ uint32_t inst_depth(const DevScene& sc, uint32_t ii) {
+    return __float_as_uint(sc.inst[2 * ii + 1].y);
+}
+// World ray → ray inside the first `levels` instances of owner's chain.
+__device__ __forceinline__ void localize(const DevScene& sc, uint32_t owner, uint32_t levels, f3 wo, f3 wd, f3& o, f3& d) {
+    o = wo;
+    d = wd;
+    for (uint32_t k = 0; k < levels; ++k) inst_apply_ray(sc, sc.inst_chain[owner * MAX_CHAIN + k], o, d);
+}
+
+// Hit back out of instance ii; `rd` is the ray direction INSIDE the instance
+// (collider.rs:484-485 translate, 513-523 rotate: set_face_normal against that ray).
+__device__ __forceinline__ void inst_apply_hit(const DevScene& sc, uint32_t ii, f3 rd, f3& p, f3& nrm, bool& front) {
+    const float4 a = sc.inst[2 * ii];
+    const uint32_t kind = __float_as_uint(a.x);
+    f3 outn = nrm;
+    if (kind == RR_INST_TRANSLATE) {
+        const float v2 = sc.inst[2 * ii + 1].x;
+        p = p + mk3(a.z, a.w, v2);
+    } else {
+        const float s = a.z, c = a.w;
+        f3 np = p;
+        if (kind == RR_INST_ROTATE_Y) {
+            np.x = c * p.x + s * p.z;
+            np.z = -s * p.x + c * p.z;
+            outn.x = c * nrm.x + s * nrm.z;
+            outn.z = -s * nrm.x + c * nrm.z;
+        } else if (kind == RR_INST_ROTATE_X) {
+            np.y = c * p.y + s * p.z;
+            np.z = -s * p.y + c * p.z;
+            outn.y = c * nrm.y + s * nrm.z;
+            outn.z = -s * nrm.y + c * nrm.z;
+        } else {
+            np.x = c * p.x + s * p.y;
+            np.y = -s * p.x + c * p.y;
+            outn.x = c * nrm.x + s * nrm.y;
+            outn.y = -s * nrm.x + c * nrm.y;
+        }
+        p = np;
+    }
+    front = dot3(rd, outn) < 0.0f;
+    nrm = front ? outn : neg3(outn);
+}
+
+// ------------------------------------------------------------ primitives
+// Each test returns the accepted t, or a negative-NaN-free "no hit" through `hit`.
+__device__ __forceinline__ bool test_sphere(f3 center, float radius, f3 o, f3 d, float tmin, float tmax, float& t) {
+    // collider.rs:278-292
+    f3 oc = o - center;
+    float a = len2(d);
+    float half_b = dot3(oc, d);
+    float cc = len2(oc) - radius * radius;
+    float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float root = (-half_b - sq) / a;
+    if (root < tmin || tmax < root) {
+        root = (-half_b + sq) / a;
+        if (root < tmin || tmax < root) return false;
+    }
+    t = root;
+    return true;
+}
+
+__device__ __forceinline__ bool test_rect(float4 q0, float k, uint32_t axis, f3 o, f3 d, float tmin, float tmax, float& t,
+                                          float& ca, float& cb) {
+    // collider.rs:344-353 / 367-376 / 405-414
+    float ok, dk, oa, da, ob, db;
+    if (axis == RR_RECT_XY) {
+        ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
+    } else if (axis == RR_RECT_XZ) {
+        ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
+    } else {
+        ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
+    }
+    float tt = (k - ok) / dk;
+    if (tt < tmin || tt > tmax) return false;
+    float a = oa + tt * da;
+    float b = ob + tt * db;
+    if (a < q0.x || a > q0.y || b < q0.z || b > q0.w) return false;
+    t = tt;
+    ca = a;
+    cb = b;
+    return true;
+}
+
+__device__ __forceinline__ bool test_triangle(const DevScene& sc, uint32_t idx, f3 o, f3 d, float& t) {
+    // collider.rs:627-661; the t range is not tested
+    const float4 q0 = sc.tri[3 * idx], q1 = sc.tri[3 * idx + 1], q2 = sc.tri[3 * idx + 2];
+    const f3 p0 = mk3(q0.x, q0.y, q0.z), p1 = mk3(q0.w, q1.x, q1.y), p2 = mk3(q1.z, q1.w, q2.x), n = mk3(q2.y, q2.z, q2.w);
+    float ndd = dot3(n, d);
+    if (fabsf(ndd) < 0.000001f) return false;
+    float dd = -dot3(n, p0);
+    float dist = -(dot3(n, o) + dd) / ndd;
+    if (dist < 0.0f) return false;
+    f3 hp = o + d * dist;
+    if (dot3(n, cross3(p1 - p0, hp - p0)) < 0.0f) return false;
+    if (dot3(n, cross3(p2 - p1, hp - p1)) < 0.0f) return false;
+    if (dot3(n, cross3(p0 - p2, hp - p2)) < 0.0f) return false;
+    t = dist;
+    return true;
+}
+
+__device__ __forceinline__ bool test_box(float4 lo, float4 hi, f3 o, f3 d, float tmin, float tmax) {
+    // aabb.rs:37-52: only axes with a negative reciprocal direction clip the interval
+    {
+        float inv = 1.0f / d.x;
+        float t0 = (lo.x - o.x) * inv, t1 = (hi.x - o.x) * inv;
+        if (inv < 0.0f) {
+            tmin = t1 > tmin ? t1 : tmin;
+            tmax = t0 < tmax ? t0 : tmax;
+        }
+        if (tmax <= tmin) return false;
+    }
+    {
+        float inv = 1.0f / d.y;
+        float t0 = (lo.y - o.y) * inv, t1 = (hi.y - o.y) * inv;
+        if (inv < 0.0f) {
+            tmin = t1 > tmin ? t1 : tmin;
+            tmax = t0 < tmax ? t0 : tmax;
+        }
+        if (tmax <= tmin) return false;
+    }
+    {
+        float inv = 1.0f / d.z;
+        float t0 = (lo.z - o.z) * inv, t1 = (hi.z - o.z) * inv;
+        if (inv < 0.0f) {
+            tmin = t1 > tmin ? t1 : tmin;
+            tmax = t0 < tmax ? t0 : tmax;
+        }
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ f3 msphere_center(float4 a, float4 b, float time) {  // collider.rs:269-271
+    f3 c0 = mk3(a.x, a.y, a.z), c1 = mk3(b.x, b.y, b.z);
+    return c0 + (c1 - c0) * ((time - a.w) / (b.w - a.w));
+}
+
+// ------------------------------------------------------- traversal machine
+// Emulates the reference's recursive intersect (collider.rs:682-697) with an explicit
+// per-lane stack.  The recursion's value — not simply the closest hit — is what is
+// reproduced: BVH children are visited in the reference's order, a first-child miss
+// re-tests `left` (collider.rs:555-561), span-1 leaves are tested twice, triangles
+// accept any t >= 0 and every accepted hit replaces the previous one.
+//
+// State: (tmin, tmax, cur).  `cur` is the primitive (or medium) of the hit that the
+// innermost pending call would return, NONE if it would return None; tmax equals that
+// hit's t whenever cur is set.  Calls that start from "no hit yet" (the first child of
+// a BVH node, a medium's boundary probes) save the caller's `cur` in their frame and
+// restore it on a miss; every other recursive call is a tail call and needs no frame.
+// Only (t, primitive) travel up the stack: point, normal, uv and the instance
+// post-transforms are recomputed once from them in reconstruct_hit().
+//
+// stk addresses this lane's stack: word w lives at stk[w * stride].
+template <bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, Rng& rng,
+                                         uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
+    f3 o = wo, d = wd;
+    uint32_t cur = NONE;
+    uint32_t sp = 0;
+    uint32_t node = sc.root;
+    for (;;) {
+        // ------------------------------------------------ evaluate `node`
+        if (node != NONE) {
+            const uint32_t tag = dtag(node), idx = didx(node);
+            if (tag == RR_TAG_BVH) {
+                const float4 lo = sc.bvh[2 * idx], hi = sc.bvh[2 * idx + 1];
+                const uint32_t left = __float_as_uint(lo.w), right = __float_as_uint(hi.w);
+                bool pass = true;
+                if (dextra(right) & 1u) {
+                    if (COUNT) cnt.box_tests++;
+                    pass = test_box(lo, hi, o, d, tmin, tmax);
+                }
+                if (pass) {
+                    const bool dirpos = comp(d, dextra(left)) >= 0.0f;
+                    stk[sp * stride] = cur;
+                    stk[(sp + 1) * stride] = F_BVH | idx;
+                    sp += 2;
+                    cur = NONE;
+                    node = (dirpos ? left : right) & ~(3u << 30);
+                } else {
+                    node = NONE;
+                }
+            } else if (tag == RR_TAG_SPHERE) {
+                if (COUNT) cnt.prim_tests++;
+                const float4 s = sc.sphere[idx];
+                float t;
+                if (test_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, tmax, t)) {
+                    tmax = t;
+                    cur = node;
+                }
+                node = NONE;
+            } else if (tag == RR_TAG_TRIANGLE) {
+                if (COUNT) cnt.prim_tests++;
+                float t;
+                if (test_triangle(sc, idx, o, d, t)) {
+                    tmax = t;
+                    cur = node;
+                }
+                node = NONE;
+            } else if (tag == RR_TAG_RECT) {
+                if (COUNT) cnt.prim_tests++;
+                const float4 q0 = sc.rect[2 * idx], q1 = sc.rect[2 * idx + 1];
+                float t, ca, cb;
+                if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
+                    tmax = t;
+                    cur = node;
+                }
+                node = NONE;
+            } else if (tag == RR_TAG_CUBOID) {
+                // six rects as a linear closest-hit list (collider.rs:428-430 → 751-772)
+                const uint32_t first = sc.cuboid[idx];
+                for (uint32_t i = 0; i < 6; ++i) {
+                    if (COUNT) cnt.prim_tests++;
+                    const float4 q0 = sc.rect[2 * (first + i)], q1 = sc.rect[2 * (first + i) + 1];
+                    float t, ca, cb;
+                    if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
+                        tmax = t;
+                        cur = dref(RR_TAG_RECT, first + i);
+                    }
+                }
+                node = NONE;
+            } else if (tag == RR_TAG_MOVING_SPHERE) {
+                if (COUNT) cnt.prim_tests++;
+                const float4 a = sc.msphere[3 * idx], b = sc.msphere[3 * idx + 1], c = sc.msphere[3 * idx + 2];
+                float t;
+                if (test_sphere(msphere_center(a, b, time), c.x, o, d, tmin, tmax, t)) {
+                    tmax = t;
+                    cur = node;
+                }
+                node = NONE;
+            } else if (tag == RR_TAG_LIST) {
+                const uint2 l = sc.list[idx];
+                if (l.y == 0) {
+                    node = NONE;
+                } else {
+                    stk[sp * stride] = l.x + 1;
+                    stk[(sp + 1) * stride] = F_LIST | idx;
+                    sp += 2;
+                    node = sc.child_refs[l.x];
+                }
+            } else if (tag == RR_TAG_INSTANCE) {
+                if (COUNT) cnt.inst_visits++;
+                stk[sp * stride] = F_INST | idx;
+                sp += 1;
+                inst_apply_ray(sc, idx, o, d);
+                node = __float_as_uint(sc.inst[2 * idx].y);
+            } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
+                if (COUNT) cnt.inst_visits++;
+                stk[sp * stride] = __float_as_uint(tmin);
+                stk[(sp + 1) * stride] = __float_as_uint(tmax);
+                stk[(sp + 2) * stride] = cur;
+                stk[(sp + 3) * stride] = 0u;
+                stk[(sp + 4) * stride] = F_MED1 | idx;
+                sp += 5;
+                tmin = -kF32Max;
+                tmax = kF32Max;
+                cur = NONE;
+                node = sc.medium[idx].x;
+            }
+        }
+        // ------------------------------------------- return to the caller
+        if (node == NONE) {
+            if (sp == 0) break;
+            const uint32_t hdr = stk[(sp - 1) * stride];
+            const uint32_t kind = hdr & F_KIND, idx = hdr & ~F_KIND;
+            if (kind == F_BVH) {
+                // collider.rs:546-580 after the first child came back
+                const uint32_t saved = stk[(sp - 2) * stride];
+                sp -= 2;
+                const uint32_t left = __float_as_uint(sc.bvh[2 * idx].w), right = __float_as_uint(sc.bvh[2 * idx + 1].w);
+                const bool dirpos = comp(d, dextra(left)) >= 0.0f;
+                if (cur != NONE) {
+                    node = (dirpos ? right : left) & ~(3u << 30);  // second child, t_max = first hit's t
+                } else {
+                    cur = saved;
+                    node = left & ~(3u << 30);  // both branches re-enter `left` after a miss
+                }
+            } else if (kind == F_LIST) {
+                const uint32_t pos = stk[(sp - 2) * stride];
+                const uint2 l = sc.list[idx];
+                if (pos < l.x + l.y) {
+                    stk[(sp - 2) * stride] = pos + 1;
+                    node = sc.child_refs[pos];
+                } else {
+                    sp -= 2;
+                }
+            } else if (kind == F_INST) {
+                sp -= 1;
+                const uint32_t depth = inst_depth(sc, idx);
+                localize(sc, idx, depth - 1, wo, wd, o, d);  // back to the enclosing space, recomputed from the world ray
+            } else if (kind == F_MED1) {
+                if (cur == NONE) {
+                    tmin = __uint_as_float(stk[(sp - 5) * stride]);
+                    tmax = __uint_as_float(stk[(sp - 4) * stride]);
+                    cur = stk[(sp - 3) * stride];
+                    sp -= 5;
+                } else {  // second probe over (t1 + 0.0001, f32::MAX), collider.rs:443
+                    const float t1 = tmax;
+                    stk[(sp - 2) * stride] = __float_as_uint(t1);
+                    stk[(sp - 1) * stride] = F_MED2 | idx;
+                    tmin = t1 + 0.0001f;
+                    tmax = kF32Max;
+                    cur = NONE;
+                    node = sc.medium[idx].x;
+                }
+            } else {  // F_MED2
+                const bool found = cur != NONE;
+                float t2 = tmax;
+                float t1 = __uint_as_float(stk[(sp - 2) * stride]);
+                tmin = __uint_as_float(stk[(sp - 5) * stride]);
+                tmax = __uint_as_float(stk[(sp - 4) * stride]);
+                cur = stk[(sp - 3) * stride];
+                sp -= 5;
+                if (found) {  // collider.rs:448-474
+                    if (t1 < tmin) t1 = tmin;
+                    if (t2 > tmax) t2 = tmax;
+                    if (t1 < t2) {
+                        if (t1 < 0.0f) t1 = 0.0f;
+                        const float ray_length = len3(d);
+                        const float dist_inside = (t2 - t1) * ray_length;
+                        const float hit_dist = __uint_as_float(sc.medium[idx].y) * log10f(rng.random());
+                        if (!(hit_dist > dist_inside)) {
+                            tmax = t1 + hit_dist / ray_length;
+                            cur = dref(RR_TAG_MEDIUM, idx);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    t_hit = tmax;
+    ref_hit = cur;
+}
+
+// ---------------------------------------------------------- hit records
+struct HitRec {
+    f3 p, n;
+    float t, u, v;
+    bool front;
+    uint32_t mat;
+};
+
+// Rebuild the HitRecord (material.rs:8-38) the reference would have returned for the
+// winning (t, primitive): evaluate the primitive in its own space, then walk the
+// enclosing instances outwards applying their hit transforms.
+__device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref,
+                                                  bool want_uv) {
+    HitRec h;
+    h.t = t;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    const uint32_t tag = dtag(ref), idx = didx(ref);
+    uint32_t owner;
+    float4 r0, r1;  // record words reused below
+    if (tag == RR_TAG_SPHERE) {
+        const uint2 m = sc.sphere_meta[idx];
+        h.mat = m.x;
+        owner = m.y;
+        r0 = sc.sphere[idx];
+    } else if (tag == RR_TAG_RECT) {
+        r0 = sc.rect[2 * idx];
+        r1 = sc.rect[2 * idx + 1];
+        h.mat = __float_as_uint(r1.z);
+        owner = __float_as_uint(r1.w);
+    } else if (tag == RR_TAG_TRIANGLE) {
+        const uint2 m = sc.tri_meta[idx];
+        h.mat = m.x;
+        owner = m.y;
+        r0 = sc.tri[3 * idx + 2];
+    } else if (tag == RR_TAG_MOVING_SPHERE) {
+        r0 = sc.msphere[3 * idx + 2];
+        h.mat = __float_as_uint(r0.y);
+        owner = __float_as_uint(r0.z);
+    } else {  // medium
+        const uint4 m = sc.medium[idx];
+        h.mat = m.z;
+        owner = m.w;
+    }
+    const uint32_t depth = owner == NONE ? 0u : inst_depth(sc, owner);
+    f3 o, d;
+    localize(sc, owner, depth, wo, wd, o, d);
+    h.p = o + d * t;
+    if (tag == RR_TAG_SPHERE || tag == RR_TAG_MOVING_SPHERE) {
+        f3 center;
+        float radius;
+        if (tag == RR_TAG_SPHERE) {
+            center = mk3(r0.x, r0.y, r0.z);
+            radius = r0.w;
+        } else {
+            center = msphere_center(sc.msphere[3 * idx], sc.msphere[3 * idx + 1], time);
+            radius = r0.x;
+        }
+        const f3 outn = (h.p - center) / radius;  // collider.rs:296
+        h.front = dot3(d, outn) < 0.0f;
+        h.n = h.front ? outn : neg3(outn);
+        if (want_uv && tag == RR_TAG_SPHERE) {  // collider.rs:272-276; moving spheres never set uv
+            const float theta = acosf(-outn.y);
+            const float phi = atan2f(-outn.z, outn.x) + kPi;
+            h.u = phi / kTau;
+            h.v = theta / kPi;
+        }
+    } else if (tag == RR_TAG_RECT) {
+        const uint32_t axis = __float_as_uint(r1.y);
+        float a, b;
+        f3 outn;
+        // a, b exactly as the intersector formed them (origin + t * direction, not Ray::at)
+        if (axis == RR_RECT_XY) {
+            a = o.x + t * d.x, b = o.y + t * d.y, outn = mk3(0.0f, 0.0f, 1.0f);
+        } else if (axis == RR_RECT_XZ) {
+            a = o.x + t * d.x, b = o.z + t * d.z, outn = mk3(0.0f, 1.0f, 0.0f);
+        } else {
+            a = o.y + t * d.y, b = o.z + t * d.z, outn = mk3(1.0f, 0.0f, 0.0f);
+        }
+        h.u = (a - r0.x) / (r0.y - r0.x);
+        h.v = (b - r0.z) / (r0.w - r0.z);
+        h.front = dot3(d, outn) < 0.0f;
+        h.n = h.front ? outn : neg3(outn);
+    } else if (tag == RR_TAG_TRIANGLE) {
+        const f3 outn = mk3(r0.y, r0.z, r0.w);
+        h.front = dot3(d, outn) < 0.0f;
+        h.n = h.front ? outn : neg3(outn);
+    } else {  // medium, collider.rs:470-473
+        h.n = mk3(1.0f, 0.0f, 0.0f);
+        h.front = true;
+    }
+    for (uint32_t k = depth; k > 0; --k) {
+        f3 ko, kd;
+        localize(sc, owner, k, wo, wd, ko, kd);  // the ray inside instance k-1 of the chain
+        inst_apply_hit(sc, sc.inst_chain[owner * MAX_CHAIN + k - 1], kd, h.p, h.n, h.front);
+    }
+    return h;
+}
+
+// ------------------------------------------------------- perlin / textures
+__device__ __forceinline__ int floor_to_int_sat(float f) {
+    // perlin.rs:69-71 casts floor() to isize and keeps the low 8 bits; of a saturated
+    // i64 those are 0xFF (positive), 0x00 (negative) and 0 for NaN
+    if (f != f) return 0;
+    if (f >= 9.2233720368547758e18f) return 0xFF;
+    if (f <= -9.2233720368547758e18f) return 0;
+    if (f >= 2147483648.0f || f < -2147483648.0f) {
+        // beyond i32: every f32 this large is a multiple of 256
+        return 0;
+    }
+    return static_cast<int>(f);
+}
+
+__device__ inline float perlin_noise(const DevScene& sc, uint32_t table, f3 p) {  // perlin.rs:47-86
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = floor_to_int_sat(fx), j = floor_to_int_sat(fy), k = floor_to_int_sat(fz);
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    const uint8_t* px = sc.perlin_perm + table * 768u;
+    const float* vec = sc.perlin_vec + table * 768u;
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const uint32_t h = px[(i + di) & 255] ^ px[256 + ((j + dj) & 255)] ^ px[512 + ((k + dk) & 255)];
+                const f3 c = mk3(vec[3 * h], vec[3 * h + 1], vec[3 * h + 2]);
+                const f3 wv = mk3(u - float(di), v - float(dj), w - float(dk));
+                accum += (float(di) * uu + (1.0f - float(di)) * (1.0f - uu)) * (float(dj) * vv + (1.0f - float(dj)) * (1.0f - vv)) *
+                         (float(dk) * ww + (1.0f - float(dk)) * (1.0f - ww)) * dot3(c, wv);
+            }
+    return accum;
+}
+
+__device__ inline float perlin_turb(const DevScene& sc, uint32_t table, f3 p, uint32_t depth) {  // perlin.rs:87-98
+    float accum = 0.0f, weight = 1.0f;
+    f3 tp = p;
+    for (uint32_t i = 0; i < depth; ++i) {
+        accum += weight * perlin_noise(sc, table, tp);
+        weight *= 0.5f;
+        tp = tp * 2.0f;
+    }
+    return fabsf(accum);
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {  // utils.rs:57-65
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+__device__ __forceinline__ uint32_t f32_as_u32_sat(float f) {  // Rust `as u32`
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return static_cast<uint32_t>(f);
+}
+
+__device__ inline f3 texture_color(const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
+    const DevTexture& t = sc.textures[tex];
+    const uint32_t type = t.type;
+    if (type == RR_TEX_SOLID) return mk3(t.c0[0], t.c0[1], t.c0[2]);
+    if (type == RR_TEX_CHECKERED) {
+        const float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+        return sines < 0.0f ? mk3(t.c0[0], t.c0[1], t.c0[2]) : mk3(t.c1[0], t.c1[1], t.c1[2]);
+    }
+    if (type == RR_TEX_NOISE) {
+        const float tv = perlin_turb(sc, t.index, p, t.depth);
+        return mk3(1.0f, 1.0f, 1.0f) * 0.5f * (1.0f + sinf(t.scale * p.z + 10.0f * tv));
+    }
+    const DevImage im = sc.images[t.index];
+    const float uc = clampf(u, 0.0f, 1.0f);
+    const float vc = 1.0f - clampf(v, 0.0f, 1.0f);
+    uint32_t i = f32_as_u32_sat(uc * float(im.width));
+    uint32_t j = f32_as_u32_sat(vc * float(im.height));
+    if (i >= im.width) i = im.width - 1;
+    if (j >= im.height) j = im.height - 1;
+    const uint8_t* px = sc.image_bytes + im.offset + (static_cast<uint64_t>(j) * im.width + i) * 3u;
+    const float cs = 1.0f / 255.0f;
+    return mk3(float(px[0]) * cs, float(px[1]) * cs, float(px[2]) * cs);
+}
+
+// ---------------------------------------------------------------- sampling
+__device__ __forceinline__ f3 random_in_unit_sphere(Rng& g) {  // vec3.rs:223-231
+    for (;;) {
+        float x = g.randrange(-1.0f, 1.0f);
+        float y = g.randrange(-1.0f, 1.0f);
+        float z = g.randrange(-1.0f, 1.0f);
+        f3 p = mk3(x, y, z);
+        if (len2(p) >= 1.0f) continue;
+        return p;
+    }
+}
+__device__ __forceinline__ f3 random_cosine_direction(Rng& g) {  // vec3.rs:257-266
+    const float r1 = g.random();
+    const float r2 = g.random();
+    const float z = sqrtf(1.0f - r2);
+    const float phi = kTau * r1;
+    const float x = cosf(phi) * sqrtf(r2);
+    const float y = sinf(phi) * sqrtf(r2);
+    return mk3(x, y, z);
+}
+__device__ __forceinline__ float reflectance(float cosin, float ref_idx) {  // material.rs:116-120
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 *= r0;
+    const float x = 1.0f - cosin;
+    return r0 + (1.0f - r0) * (x * x * x * x * x);
+}
+
+__device__ __forceinline__ float light_pdf_value(const DevScene& sc, f3 origin, f3 v) {  // collider.rs:389-399, 714-719
+    if (!sc.light_is_xzrect) return 0.0f;
+    float t, ca, cb;
+    if (!test_rect(make_float4(sc.light_x0, sc.light_x1, sc.light_z0, sc.light_z1), sc.light_k, RR_RECT_XZ, origin, v, 0.001f,
+                   kF32Max, t, ca, cb))
+        return 0.0f;
+    const f3 outn = mk3(0.0f, 1.0f, 0.0f);
+    const f3 n = dot3(v, outn) < 0.0f ? outn : neg3(outn);
+    const float area = (sc.light_x1 - sc.light_x0) * (sc.light_z1 - sc.light_z0);
+    const float dist_sqrd = t * t * len2(v);
+    const float cosine = fabsf(dot3(v, n) / len3(v));
+    return dist_sqrd / (cosine * area);
+}
+
+// One ray_color call (render.rs:15-41) minus the recursion.  Returns true when the
+// path goes on with ray (o, d) and its throughput multiplied by `weight`; returns
+// false when it ends with radiance `terminal` (background, emitted light, or the
+// emitted colour of a surface that does not scatter).
+struct Bounce {
+    f3 o, d;
+    f3 weight;
+    f3 terminal;
+};
+__device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, Rng& g, Bounce& out) {
+    if (ref == NONE) {
+        out.terminal = ld3(sc.background);
+        return false;
+    }
+    // which records need u,v: only image textures read them
+    HitRec rec;
+    {
+        // material id is needed before reconstruct can know about uv, so reconstruct asks for
+        // uv whenever the scene has images at all
+        rec = reconstruct_hit(sc, wo, wd, time, t, ref, sc.images != nullptr);
+    }
+    const DevMaterial m = sc.materials[rec.mat];
+    f3 attenuation;
+    if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
+        out.terminal = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+        return false;
+    }
+    if (m.type == RR_MAT_LAMBERTIAN) {  // material.rs:85-92: two draws for a direction nobody uses
+        rng_skip(g, 2);
+        attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+    } else if (m.type == RR_MAT_GLOSSY) {  // material.rs:121-126
+        const f3 reflected = unit3(wd) - rec.n * 2.0f * dot3(unit3(wd), rec.n);
+        const f3 sd = reflected + random_in_unit_sphere(g) * m.param;
+        attenuation = mk3(m.r, m.g, m.b);
+        if (!(dot3(sd, rec.n) > 0.0f)) {
+            out.terminal = mk3(0.0f, 0.0f, 0.0f);
+            return false;
+        }
+    } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: one draw unless total internal reflection
+        attenuation = mk3(1.0f, 1.0f, 1.0f);
+        const float ratio = rec.front ? 1.0f / m.param : m.param;
+        const f3 ud = unit3(wd);
+        const float cos_theta = fminf(dot3(neg3(ud), rec.n), 1.0f);
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        if (!(ratio * sin_theta > 1.0f)) rng_skip(g, 1);
+    } else {  // isotropic, material.rs:150-154
+        (void)random_in_unit_sphere(g);
+        attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+    }
+    // render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal
+    const f3 w = unit3(rec.n);  // vec3.rs:205-215
+    const f3 a = fabsf(w.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    const f3 v = unit3(cross3(w, a));
+    const f3 u = cross3(w, v);
+    f3 dir;
+    if (g.random() < 0.5f) {  // pdf.rs:51-53 → collider.rs:400-403 / 720-725
+        if (sc.light_is_xzrect) {
+            const float x = g.randrange(sc.light_x0, sc.light_x1);
+            const float z = g.randrange(sc.light_z0, sc.light_z1);
+            dir = mk3(x, sc.light_k, z) - rec.p;
+        } else {
+            dir = mk3(1.0f, 0.0f, 0.0f);
+        }
+    } else {
+        const f3 cd = random_cosine_direction(g);
+        dir = u * cd.x + v * cd.y + w * cd.z;
+    }
+    const f3 udir = unit3(dir);
+    const float cosin = dot3(udir, w);  // pdf.rs:33-36
+    const float cos_pdf = cosin <= 0.0f ? 0.0f : cosin / kPi;
+    const float pdf_val = 0.5f * light_pdf_value(sc, rec.p, dir) + 0.5f * cos_pdf;  // pdf.rs:48-50
+    float sp = 0.0f;  // material.rs:170-175: every non-Lambertian material has scattering pdf 0
+    if (m.type == RR_MAT_LAMBERTIAN) {
+        const float cs = dot3(rec.n, udir);
+        sp = cs < 0.0f ? 0.0f : cs / kPi;
+    }
+    out.o = rec.p;
+    out.d = dir;
+    out.weight = (attenuation * sp) / pdf_val;  // render.rs:34, applied front to back
+    return true;
+}
+
+// Camera::get_ray (camera.rs:76-84) after the pixel jitter of render.rs:96-97.
+__device__ __forceinline__ void camera_ray(const DevScene& sc, uint32_t width, uint32_t height, uint32_t i, uint32_t j, Rng& g,
+                                           f3& o, f3& d, float& time) {
+    const float u = (float(i) + g.random()) / (float(width) - 1.0f);
+    const float v = (float(j) + g.random()) / (float(height) - 1.0f);
+    float dx, dy;
+    for (;;) {  // vec3.rs:247-255
+        dx = g.randrange(-1.0f, 1.0f);
+        dy = g.randrange(-1.0f, 1.0f);
+        if (dx * dx + dy * dy + 0.0f * 0.0f >= 1.0f) continue;
+        break;
+    }
+    const f3 rd = mk3(dx, dy, 0.0f) * sc.cam.lens_radius;
+    const f3 offset = ld3(sc.cam.u) * rd.x + ld3(sc.cam.v) * rd.y;
+    const f3 origin = ld3(sc.cam.origin);
+    o = origin + offset;
+    d = ld3(sc.cam.lower_left) + ld3(sc.cam.horizontal) * u + ld3(sc.cam.vertical) * v - origin - offset;
+    time = g.randrange(sc.cam.shutter_open, sc.cam.shutter_close);
+}
+
+}  // namespace rrdev

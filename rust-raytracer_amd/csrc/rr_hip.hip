@@ -1,0 +1,820 @@
+// librr_hip.so — kernels, scene upload and the C ABI of include/rr_hip.h for gfx950.
+//
+// One persistent path-tracing kernel does the work of render_worker + ray_color
+// (src/render.rs:15-41, 89-124): every lane owns one (slice, pixel) work item at a
+// time, runs that pixel's samples one after the other (so the f32 pixel sum is added
+// in the reference's order, with no atomics), and starts its next camera ray the
+// moment a path ends, so that all 64 lanes of a wave stay busy whatever the path
+// lengths are.  Lanes of a wave hold the 64 pixels of one 8x8 tile.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rr_device.h"
+
+using namespace rrdev;
+
+// ================================================================= kernels
+struct RenderArgs {
+    uint32_t width, height;
+    uint32_t spt;           // samples per slice and pixel (render.rs:130)
+    uint32_t tiles_x;       // 8x8 pixel tiles per row
+    uint32_t padded_pixels; // tiles * 64
+    uint64_t n_items;       // slices in this launch * padded_pixels
+    uint32_t slice_first;   // absolute index of the launch's first slice
+    uint32_t slice_out;     // index of that slice inside the output buffer
+    uint32_t max_depth;
+    uint32_t sample_offset;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_down(static_cast<unsigned>(v), off, 64);
+        unsigned hi = __shfl_down(static_cast<unsigned>(v >> 32), off, 64);
+        v += (static_cast<unsigned long long>(hi) << 32) | lo;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* counters) {
+    if (!counters) return;
+    unsigned long long v[5] = {c.samples, c.rays, c.box_tests, c.prim_tests, c.inst_visits};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        unsigned long long s = wave_sum(v[i]);
+        if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&counters[i], s);
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
+                                                unsigned long long* counters) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint64_t item_stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+
+    Counts cnt = {0, 0, 0, 0, 0};
+    bool have_item = false, path_active = false;
+    uint32_t px = 0, py = 0, sl = 0, s = 0;
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(0.f, 0.f, 0.f), thr = mk3(1.f, 1.f, 1.f);
+    float time = 0.f;
+    uint32_t depth_left = 0, bounce = 0, sample = 0, pixel_key = 0;
+
+    for (;;) {
+        if (!path_active) {
+            if (!have_item) {
+                bool found = false;
+                while (q < a.n_items) {
+                    const uint32_t r = static_cast<uint32_t>(q % a.padded_pixels);
+                    sl = static_cast<uint32_t>(q / a.padded_pixels);
+                    const uint32_t tile = r >> 6, within = r & 63u;
+                    px = (tile % a.tiles_x) * 8u + (within & 7u);
+                    py = (tile / a.tiles_x) * 8u + (within >> 3);
+                    if (px < a.width && py < a.height) {
+                        found = true;
+                        break;
+                    }
+                    q += item_stride;
+                }
+                if (!found) break;
+                have_item = true;
+                s = 0;
+                acc = mk3(0.f, 0.f, 0.f);
+                pixel_key = py * a.width + px;
+            }
+            if (s == a.spt) {  // pixel_color of render.rs:93-100 is complete for this slice
+                float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.height + py) * a.width + px) * 3u;
+                dst[0] = acc.x;
+                dst[1] = acc.y;
+                dst[2] = acc.z;
+                have_item = false;
+                q += item_stride;
+                continue;
+            }
+            sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
+            Rng g;
+            g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
+            camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
+            thr = mk3(1.f, 1.f, 1.f);
+            depth_left = a.max_depth;
+            bounce = 0;
+            path_active = true;
+            cnt.samples++;
+        }
+        // one ray_color call (render.rs:15-41)
+        f3 terminal = mk3(0.f, 0.f, 0.f);
+        bool go_on = false;
+        if (depth_left != 0) {
+            cnt.rays++;
+            Rng g;
+            g.start(a.seed, pixel_key, sample, bounce);
+            float t;
+            uint32_t ref;
+            traverse<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, g, stk, stride, t, ref, cnt);
+            Bounce b;
+            go_on = shade(sc, ro, rd, time, t, ref, g, b);
+            if (go_on) {
+                ro = b.o;
+                rd = b.d;
+                thr = thr * b.weight;
+                depth_left -= 1;
+                bounce += 1;
+            } else {
+                terminal = b.terminal;
+            }
+        }
+        if (!go_on) {
+            acc = acc + thr * terminal;  // render.rs:99
+            s += 1;
+            path_active = false;
+        }
+    }
+    flush_counts(cnt, counters);
+}
+
+__global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, const float* __restrict__ rays, float t_min,
+                                                      float t_max, uint64_t seed, float* __restrict__ out_f,
+                                                      uint32_t* __restrict__ out_ref) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + static_cast<uint64_t>(i) * 7u;
+    const f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+    const float time = r[6];
+    Rng g;
+    g.start(seed, i, 0, 0);
+    Counts cnt = {0, 0, 0, 0, 0};
+    float t;
+    uint32_t ref;
+    traverse<false>(sc, o, d, time, t_min, t_max, g, stk, blockDim.x, t, ref, cnt);
+    float* of = out_f + static_cast<uint64_t>(i) * 12u;
+    out_ref[i] = ref;
+    if (ref == NONE) {
+        for (int k = 0; k < 12; ++k) of[k] = 0.f;
+        return;
+    }
+    const HitRec h = reconstruct_hit(sc, o, d, time, t, ref, true);
+    of[0] = h.t;
+    of[1] = h.p.x, of[2] = h.p.y, of[3] = h.p.z;
+    of[4] = h.n.x, of[5] = h.n.y, of[6] = h.n.z;
+    of[7] = h.u, of[8] = h.v;
+    of[9] = __uint_as_float(h.front ? 1u : 0u);
+    of[10] = __uint_as_float(h.mat);
+    of[11] = 0.f;
+}
+
+// render.rs:102-119 per slice, summed over the slices in slice order (render.rs:141-150).
+__global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ slice_sums, uint32_t n_slices_here, uint64_t n_elems,
+                                                 float scale, float n_threads, float* __restrict__ resolved,
+                                                 float* __restrict__ linear) {
+    const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= n_elems) return;
+    float acc_res = 0.f, acc_lin = 0.f;
+    for (uint32_t k = 0; k < n_slices_here; ++k) {
+        float c = slice_sums[static_cast<uint64_t>(k) * n_elems + e];
+        if (c != c) c = 0.f;
+        acc_lin += c;
+        const float g = sqrtf(scale * c);
+        acc_res += 256.0f * clampf(g / n_threads, 0.0f, 0.999f);
+    }
+    if (resolved) resolved[e] = acc_res;
+    if (linear) linear[e] = acc_lin;
+}
+
+// render.rs:156-159: Rust's saturating `as u8` (NaN → 0).
+__global__ void __launch_bounds__(256) k_cast_u8(const float* __restrict__ src, uint8_t* __restrict__ dst, uint64_t n) {
+    const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float f = src[e];
+    uint8_t v = 0;
+    if (f > 0.0f) v = f >= 255.0f ? 255 : static_cast<uint8_t>(f);
+    dst[e] = v;
+}
+
+// ============================================================ host side
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct DeviceBuffers {
+    std::vector<void*> ptrs;
+    uint64_t bytes = 0;
+    void release() {
+        for (void* p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct rr_context {
+    int device = 0;
+    int n_cus = 0;
+    bool has_scene = false;
+    DevScene sc{};
+    DeviceBuffers scene_mem;
+    rr_scene_info info{};
+    // ref → prim_id tables for rr_primary_hits (host side)
+    std::vector<uint32_t> id_sphere, id_msphere, id_rect, id_tri, id_medium;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int max_dynamic_lds = 0;
+};
+
+namespace {
+
+// ------------------------------------------------------- scene validation
+struct Walker {
+    const rr_flat_scene& s;
+    std::vector<uint8_t> seen[RR_TAG_COUNT];
+    std::vector<uint32_t> owner_sphere, owner_msphere, owner_rect, owner_tri, owner_medium;
+    std::vector<uint32_t> inst_depth, inst_chain;
+    uint32_t max_inst_depth = 0;
+    std::string err;
+    int err_code = RR_E_INVALID;
+
+    explicit Walker(const rr_flat_scene& sc) : s(sc) {
+        const uint32_t counts[RR_TAG_COUNT] = {s.n_spheres, s.n_moving_spheres, s.n_rects,     s.n_triangles, s.n_cuboids,
+                                               s.n_media,   s.n_instances,      s.n_bvh_nodes, s.n_lists};
+        for (uint32_t t = 0; t < RR_TAG_COUNT; ++t) seen[t].assign(counts[t], 0);
+        owner_sphere.assign(s.n_spheres, NONE);
+        owner_msphere.assign(s.n_moving_spheres, NONE);
+        owner_rect.assign(s.n_rects, NONE);
+        owner_tri.assign(s.n_triangles, NONE);
+        owner_medium.assign(s.n_media, NONE);
+        inst_depth.assign(s.n_instances, 0);
+        inst_chain.assign(static_cast<size_t>(s.n_instances) * MAX_CHAIN, NONE);
+    }
+
+    bool bad(const std::string& m, int code = RR_E_INVALID) {
+        if (err.empty()) {
+            err = m;
+            err_code = code;
+        }
+        return false;
+    }
+
+    bool mat_ok(uint32_t m) { return m < s.n_materials || bad("primitive references a material outside the table"); }
+
+    // Returns the stack words evaluating `ref` can need, or fails.  `owner` is the
+    // innermost enclosing instance; depth bounds recursion (and rejects cycles together
+    // with the visited marks).
+    bool walk(uint32_t ref, uint32_t owner, uint32_t level, uint32_t& words) {
+        if (level > 128) return bad("scene tree deeper than 128 levels (or cyclic)", RR_E_LIMIT);
+        const uint32_t tag = RR_REF_TAG(ref), idx = RR_REF_INDEX(ref);
+        if (tag >= RR_TAG_COUNT || idx >= seen[tag].size()) return bad("geometry ref out of range");
+        if (seen[tag][idx]++) return bad("a record is reachable twice: the flattened scene must be a tree (only a BVH node may name one child on both sides)");
+        words = 0;
+        switch (tag) {
+            case RR_TAG_SPHERE:
+                owner_sphere[idx] = owner;
+                return mat_ok(s.spheres[idx].material);
+            case RR_TAG_MOVING_SPHERE:
+                owner_msphere[idx] = owner;
+                return mat_ok(s.moving_spheres[idx].material);
+            case RR_TAG_RECT:
+                owner_rect[idx] = owner;
+                if (s.rects[idx].axis > RR_RECT_YZ) return bad("rect axis out of range");
+                return mat_ok(s.rects[idx].material);
+            case RR_TAG_TRIANGLE:
+                owner_tri[idx] = owner;
+                return mat_ok(s.triangles[idx].material);
+            case RR_TAG_CUBOID: {
+                const uint32_t first = s.cuboids[idx].first_rect;
+                if (first > s.n_rects || s.n_rects - first < 6) return bad("cuboid rect range out of bounds");
+                for (uint32_t i = 0; i < 6; ++i) {
+                    uint32_t w;
+                    if (!walk(RR_REF(RR_TAG_RECT, first + i), owner, level + 1, w)) return false;
+                }
+                return true;
+            }
+            case RR_TAG_MEDIUM: {
+                owner_medium[idx] = owner;
+                if (!mat_ok(s.media[idx].material)) return false;
+                uint32_t w;
+                if (!walk(s.media[idx].boundary, owner, level + 1, w)) return false;
+                words = FRAME_WORDS_MEDIUM + w;
+                return true;
+            }
+            case RR_TAG_INSTANCE: {
+                const rr_instance& in = s.instances[idx];
+                if (in.kind > RR_INST_ROTATE_Z) return bad("instance kind out of range");
+                const uint32_t depth = owner == NONE ? 1u : inst_depth[owner] + 1u;
+                if (depth > MAX_CHAIN) return bad("instances nested deeper than 8", RR_E_LIMIT);
+                inst_depth[idx] = depth;
+                for (uint32_t k = 0; k + 1 < depth; ++k) inst_chain[idx * MAX_CHAIN + k] = inst_chain[owner * MAX_CHAIN + k];
+                inst_chain[idx * MAX_CHAIN + depth - 1] = idx;
+                max_inst_depth = std::max(max_inst_depth, depth);
+                uint32_t w;
+                if (!walk(in.child, idx, level + 1, w)) return false;
+                words = FRAME_WORDS_INST + w;
+                return true;
+            }
+            case RR_TAG_BVH: {
+                const rr_bvh_node& n = s.bvh_nodes[idx];
+                if (n.axis > 2) return bad("BVH node axis out of range");
+                uint32_t wl = 0, wr = 0;
+                if (!walk(n.left, owner, level + 1, wl)) return false;
+                if (n.right != n.left) {
+                    if (!walk(n.right, owner, level + 1, wr)) return false;
+                } else {
+                    wr = wl;
+                }
+                words = FRAME_WORDS_BVH + std::max(wl, wr);
+                return true;
+            }
+            case RR_TAG_LIST: {
+                const rr_list& l = s.lists[idx];
+                if (l.first_child > s.n_child_refs || s.n_child_refs - l.first_child < l.n_children)
+                    return bad("list child range out of bounds");
+                uint32_t wmax = 0;
+                for (uint32_t i = 0; i < l.n_children; ++i) {
+                    uint32_t w;
+                    if (!walk(s.child_refs[l.first_child + i], owner, level + 1, w)) return false;
+                    wmax = std::max(wmax, w);
+                }
+                words = FRAME_WORDS_LIST + wmax;
+                return true;
+            }
+        }
+        return bad("unknown tag");
+    }
+};
+
+uint32_t to_dref(uint32_t ref, uint32_t extra = 0) { return dref(RR_REF_TAG(ref), RR_REF_INDEX(ref), extra); }
+
+template <class T>
+int upload(DeviceBuffers& mem, const std::vector<T>& host, const T** out) {
+    *out = nullptr;
+    if (host.empty()) return RR_OK;
+    void* p = nullptr;
+    const size_t bytes = host.size() * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    mem.ptrs.push_back(p);
+    mem.bytes += bytes;
+    HIP_TRY(hipMemcpy(p, host.data(), bytes, hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return RR_OK;
+}
+
+float u2f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+int set_device(rr_context* ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RR_OK;
+}
+
+int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
+    if (per_cu < 1) return fail(RR_E_LIMIT, "the scene's traversal stack does not fit the LDS of one CU");
+    per_cu = std::min(per_cu, 8);
+    *grid = ctx->n_cus * per_cu;
+    return RR_OK;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+const char* rr_last_error(void) { return g_err.c_str(); }
+
+int rr_device_count(int* count) {
+    if (!count) return fail(RR_E_INVALID, "rr_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;  // hipErrorNoDevice on a host without a GPU
+    *count = n;
+    return RR_OK;
+}
+
+int rr_context_create(int device, rr_context** out) {
+    if (!out) return fail(RR_E_INVALID, "rr_context_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RR_E_NO_DEVICE, "no HIP device visible; this library has no CPU path");
+    if (device < 0 || device >= n) return fail(RR_E_NO_DEVICE, "device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RR_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIP_TRY(hipSetDevice(device));
+    rr_context* ctx = new rr_context();
+    ctx->device = device;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->max_dynamic_lds = static_cast<int>(prop.sharedMemPerBlock);
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(RR_E_HIP, "hipEventCreate failed");
+    }
+    *out = ctx;
+    return RR_OK;
+}
+
+int rr_context_destroy(rr_context* ctx) {
+    if (!ctx) return RR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->scene_mem.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return RR_OK;
+}
+
+int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
+    if (!ctx || !s) return fail(RR_E_INVALID, "rr_scene_upload: NULL argument");
+    if (int rc = set_device(ctx)) return rc;
+    // ---- validate
+    const uint32_t counts[] = {s->n_spheres, s->n_moving_spheres, s->n_rects, s->n_triangles, s->n_cuboids,
+                               s->n_media,   s->n_instances,      s->n_bvh_nodes, s->n_lists};
+    const void* ptrs[] = {s->spheres, s->moving_spheres, s->rects, s->triangles, s->cuboids, s->media, s->instances, s->bvh_nodes, s->lists};
+    for (int i = 0; i < 9; ++i) {
+        if (counts[i] && !ptrs[i]) return fail(RR_E_INVALID, "rr_scene_upload: a non-empty array has a NULL pointer");
+        if (counts[i] > IDX_MASK) return fail(RR_E_LIMIT, "rr_scene_upload: more than 2^26 records of one kind");
+    }
+    if ((s->n_child_refs && !s->child_refs) || (s->n_materials && !s->materials) || (s->n_textures && !s->textures) ||
+        (s->n_perlin && !s->perlin) || (s->n_images && !s->images) || (s->n_image_bytes && !s->image_bytes))
+        return fail(RR_E_INVALID, "rr_scene_upload: a non-empty array has a NULL pointer");
+    if (RR_REF_TAG(s->root) != RR_TAG_LIST || RR_REF_INDEX(s->root) >= s->n_lists)
+        return fail(RR_E_INVALID, "rr_scene_upload: root must be a list ref");
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const rr_material& m = s->materials[i];
+        if (m.type > RR_MAT_EMISSIVE) return fail(RR_E_INVALID, "material type out of range");
+        if ((m.type == RR_MAT_LAMBERTIAN || m.type == RR_MAT_ISOTROPIC || m.type == RR_MAT_EMISSIVE) && m.texture >= s->n_textures)
+            return fail(RR_E_INVALID, "material references a texture outside the table");
+    }
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const rr_texture& t = s->textures[i];
+        if (t.type > RR_TEX_IMAGE) return fail(RR_E_INVALID, "texture type out of range");
+        if (t.type == RR_TEX_NOISE && t.index >= s->n_perlin) return fail(RR_E_INVALID, "noise texture references a Perlin table outside the array");
+        if (t.type == RR_TEX_IMAGE && t.index >= s->n_images) return fail(RR_E_INVALID, "image texture references an image outside the array");
+    }
+    for (uint32_t i = 0; i < s->n_images; ++i) {
+        const rr_image& im = s->images[i];
+        const uint64_t need = static_cast<uint64_t>(im.width) * im.height * 3u;
+        if (im.width == 0 || im.height == 0 || im.offset > s->n_image_bytes || s->n_image_bytes - im.offset < need)
+            return fail(RR_E_INVALID, "image outside image_bytes");
+    }
+    Walker wk(*s);
+    uint32_t stack_words = 0;
+    if (!wk.walk(s->root, NONE, 0, stack_words)) return fail(wk.err_code, "rr_scene_upload: " + wk.err);
+    stack_words = std::max(stack_words, 1u);
+    const size_t lds_bytes = static_cast<size_t>(stack_words) * 256u * 4u;
+    if (lds_bytes > static_cast<size_t>(ctx->max_dynamic_lds))
+        return fail(RR_E_LIMIT, "rr_scene_upload: traversal stack of " + std::to_string(stack_words) +
+                                    " words per lane exceeds the LDS available to one workgroup");
+
+    // ---- pack
+    std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2);
+    for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
+        const rr_bvh_node& n = s->bvh_nodes[i];
+        bvh[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], u2f(to_dref(n.left, n.axis)));
+        bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, n.has_box ? 1u : 0u)));
+    }
+    std::vector<float4> sphere(s->n_spheres);
+    std::vector<uint2> sphere_meta(s->n_spheres);
+    ctx->id_sphere.resize(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const rr_sphere& p = s->spheres[i];
+        sphere[i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
+        sphere_meta[i] = make_uint2(p.material, wk.owner_sphere[i]);
+        ctx->id_sphere[i] = p.prim_id;
+    }
+    std::vector<float4> msphere(static_cast<size_t>(s->n_moving_spheres) * 3);
+    ctx->id_msphere.resize(s->n_moving_spheres);
+    for (uint32_t i = 0; i < s->n_moving_spheres; ++i) {
+        const rr_moving_sphere& p = s->moving_spheres[i];
+        msphere[3 * i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.time0);
+        msphere[3 * i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time1);
+        msphere[3 * i + 2] = make_float4(p.radius, u2f(p.material), u2f(wk.owner_msphere[i]), 0.f);
+        ctx->id_msphere[i] = p.prim_id;
+    }
+    std::vector<float4> rect(static_cast<size_t>(s->n_rects) * 2);
+    ctx->id_rect.resize(s->n_rects);
+    for (uint32_t i = 0; i < s->n_rects; ++i) {
+        const rr_rect& p = s->rects[i];
+        rect[2 * i] = make_float4(p.a0, p.a1, p.b0, p.b1);
+        rect[2 * i + 1] = make_float4(p.k, u2f(p.axis), u2f(p.material), u2f(wk.owner_rect[i]));
+        ctx->id_rect[i] = p.prim_id;
+    }
+    std::vector<float4> tri(static_cast<size_t>(s->n_triangles) * 3);
+    std::vector<uint2> tri_meta(s->n_triangles);
+    ctx->id_tri.resize(s->n_triangles);
+    for (uint32_t i = 0; i < s->n_triangles; ++i) {
+        const rr_triangle& p = s->triangles[i];
+        tri[3 * i] = make_float4(p.p0[0], p.p0[1], p.p0[2], p.p1[0]);
+        tri[3 * i + 1] = make_float4(p.p1[1], p.p1[2], p.p2[0], p.p2[1]);
+        tri[3 * i + 2] = make_float4(p.p2[2], p.normal[0], p.normal[1], p.normal[2]);
+        tri_meta[i] = make_uint2(p.material, wk.owner_tri[i]);
+        ctx->id_tri[i] = p.prim_id;
+    }
+    std::vector<uint32_t> cuboid(s->n_cuboids);
+    for (uint32_t i = 0; i < s->n_cuboids; ++i) cuboid[i] = s->cuboids[i].first_rect;
+    std::vector<uint4> medium(s->n_media);
+    ctx->id_medium.resize(s->n_media);
+    for (uint32_t i = 0; i < s->n_media; ++i) {
+        const rr_medium& p = s->media[i];
+        uint32_t nid;
+        std::memcpy(&nid, &p.neg_inv_density, 4);
+        medium[i] = make_uint4(to_dref(p.boundary), nid, p.material, wk.owner_medium[i]);
+        ctx->id_medium[i] = p.prim_id;
+    }
+    std::vector<float4> inst(static_cast<size_t>(s->n_instances) * 2);
+    for (uint32_t i = 0; i < s->n_instances; ++i) {
+        const rr_instance& p = s->instances[i];
+        inst[2 * i] = make_float4(u2f(p.kind), u2f(to_dref(p.child)), p.v[0], p.v[1]);
+        inst[2 * i + 1] = make_float4(p.v[2], u2f(wk.inst_depth[i]), 0.f, 0.f);
+    }
+    std::vector<uint2> list(s->n_lists);
+    for (uint32_t i = 0; i < s->n_lists; ++i) list[i] = make_uint2(s->lists[i].first_child, s->lists[i].n_children);
+    std::vector<uint32_t> child_refs(s->n_child_refs);
+    for (uint32_t i = 0; i < s->n_child_refs; ++i) child_refs[i] = to_dref(s->child_refs[i]);
+    std::vector<DevMaterial> materials(s->n_materials);
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const rr_material& m = s->materials[i];
+        materials[i] = DevMaterial{m.type, m.texture, m.color[0], m.color[1], m.color[2], m.param, 0, 0};
+    }
+    std::vector<DevTexture> textures(s->n_textures);
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const rr_texture& t = s->textures[i];
+        DevTexture d{};
+        d.type = t.type;
+        d.index = t.index;
+        d.depth = t.depth;
+        d.scale = t.scale;
+        for (int k = 0; k < 3; ++k) {
+            d.c0[k] = t.color0[k];
+            d.c1[k] = t.color1[k];
+        }
+        textures[i] = d;
+    }
+    std::vector<float> perlin_vec(static_cast<size_t>(s->n_perlin) * 768);
+    std::vector<uint8_t> perlin_perm(static_cast<size_t>(s->n_perlin) * 768);
+    for (uint32_t i = 0; i < s->n_perlin; ++i) {
+        std::memcpy(&perlin_vec[static_cast<size_t>(i) * 768], s->perlin[i].ranvec, 768 * sizeof(float));
+        std::memcpy(&perlin_perm[static_cast<size_t>(i) * 768], s->perlin[i].perm_x, 256);
+        std::memcpy(&perlin_perm[static_cast<size_t>(i) * 768 + 256], s->perlin[i].perm_y, 256);
+        std::memcpy(&perlin_perm[static_cast<size_t>(i) * 768 + 512], s->perlin[i].perm_z, 256);
+    }
+    std::vector<DevImage> images(s->n_images);
+    for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
+    std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
+
+    // ---- upload (replacing any previous scene)
+    (void)hipDeviceSynchronize();
+    ctx->scene_mem.release();
+    ctx->has_scene = false;
+    DevScene d{};
+    DeviceBuffers& mem = ctx->scene_mem;
+    int rc = RR_OK;
+    if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &d.sphere_meta)) ||
+        (rc = upload(mem, msphere, &d.msphere)) || (rc = upload(mem, rect, &d.rect)) || (rc = upload(mem, tri, &d.tri)) ||
+        (rc = upload(mem, tri_meta, &d.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
+        (rc = upload(mem, inst, &d.inst)) || (rc = upload(mem, wk.inst_chain, &d.inst_chain)) || (rc = upload(mem, list, &d.list)) ||
+        (rc = upload(mem, child_refs, &d.child_refs)) || (rc = upload(mem, materials, &d.materials)) ||
+        (rc = upload(mem, textures, &d.textures)) || (rc = upload(mem, perlin_vec, &d.perlin_vec)) ||
+        (rc = upload(mem, perlin_perm, &d.perlin_perm)) || (rc = upload(mem, images, &d.images)) ||
+        (rc = upload(mem, image_bytes, &d.image_bytes))) {
+        mem.release();
+        return rc;
+    }
+    d.root = to_dref(s->root);
+    d.light_is_xzrect = s->light.is_xzrect ? 1u : 0u;
+    d.light_x0 = s->light.x0;
+    d.light_x1 = s->light.x1;
+    d.light_z0 = s->light.z0;
+    d.light_z1 = s->light.z1;
+    d.light_k = s->light.k;
+    d.cam = s->camera;
+    for (int k = 0; k < 3; ++k) d.background[k] = s->background[k];
+    ctx->sc = d;
+    ctx->info = rr_scene_info{};
+    ctx->info.stack_words = stack_words;
+    ctx->info.max_inst_depth = wk.max_inst_depth;
+    ctx->info.device_bytes = mem.bytes;
+    ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
+    ctx->has_scene = true;
+    return RR_OK;
+}
+
+int rr_scene_info_get(rr_context* ctx, rr_scene_info* out) {
+    if (!ctx || !out) return fail(RR_E_INVALID, "rr_scene_info_get: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "no scene uploaded");
+    *out = ctx->info;
+    return RR_OK;
+}
+
+int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min, float t_max, uint64_t seed, rr_hit* out) {
+    if (!ctx || (n && (!rays || !out))) return fail(RR_E_INVALID, "rr_primary_hits: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_primary_hits: no scene uploaded");
+    if (n == 0) return RR_OK;
+    if (int rc = set_device(ctx)) return rc;
+    float *d_rays = nullptr, *d_out = nullptr;
+    uint32_t* d_ref = nullptr;
+    auto cleanup = [&]() {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ref) (void)hipFree(d_ref);
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&d_rays, static_cast<size_t>(n) * 7 * 4)) != hipSuccess || (e = hipMalloc(&d_out, static_cast<size_t>(n) * 12 * 4)) != hipSuccess ||
+        (e = hipMalloc(&d_ref, static_cast<size_t>(n) * 4)) != hipSuccess ||
+        (e = hipMemcpy(d_rays, rays, static_cast<size_t>(n) * 7 * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return fail(RR_E_HIP, std::string("rr_primary_hits: ") + hipGetErrorString(e));
+    }
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    const uint32_t grid = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_primary_hits, dim3(grid), dim3(256), lds, 0, ctx->sc, n, d_rays, t_min, t_max, seed, d_out, d_ref);
+    std::vector<float> hf(static_cast<size_t>(n) * 12);
+    std::vector<uint32_t> hr(n);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(hf.data(), d_out, hf.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(hr.data(), d_ref, hr.size() * 4, hipMemcpyDeviceToHost)) != hipSuccess) {
+        cleanup();
+        return fail(RR_E_HIP, std::string("rr_primary_hits: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    for (uint32_t i = 0; i < n; ++i) {
+        rr_hit& h = out[i];
+        std::memset(&h, 0, sizeof(h));
+        const uint32_t ref = hr[i];
+        if (ref == NONE) {
+            h.prim_id = -1;
+            continue;
+        }
+        const uint32_t tag = dtag(ref), idx = didx(ref);
+        uint32_t pid = 0;
+        switch (tag) {
+            case RR_TAG_SPHERE: pid = ctx->id_sphere[idx]; break;
+            case RR_TAG_MOVING_SPHERE: pid = ctx->id_msphere[idx]; break;
+            case RR_TAG_RECT: pid = ctx->id_rect[idx]; break;
+            case RR_TAG_TRIANGLE: pid = ctx->id_tri[idx]; break;
+            default: pid = ctx->id_medium[idx]; break;
+        }
+        const float* f = &hf[static_cast<size_t>(i) * 12];
+        h.prim_id = static_cast<int32_t>(pid);
+        h.t = f[0];
+        std::memcpy(h.point, f + 1, 12);
+        std::memcpy(h.normal, f + 4, 12);
+        h.u = f[7];
+        h.v = f[8];
+        std::memcpy(&h.front_face, f + 9, 4);
+        std::memcpy(&h.material, f + 10, 4);
+    }
+    return RR_OK;
+}
+
+int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear,
+                     void* d_counters, void* hip_stream) {
+    if (!ctx || !p || !d_slice_sums) return fail(RR_E_INVALID, "rr_render_device: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_render_device: no scene uploaded");
+    if (p->width == 0 || p->height == 0 || p->n_slices == 0 || p->slice_begin > p->slice_end || p->slice_end > p->n_slices)
+        return fail(RR_E_INVALID, "rr_render_device: bad image size or slice range");
+    if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull) return fail(RR_E_LIMIT, "rr_render_device: more than 2^32 pixels");
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const uint32_t n_sl = p->slice_end - p->slice_begin;
+    const uint32_t spt = p->samples_per_pixel / p->n_slices;
+    const bool count = (p->flags & RR_FLAG_COUNTERS) != 0;
+    const void* kernel = count ? reinterpret_cast<const void*>(&k_render<true>) : reinterpret_cast<const void*>(&k_render<false>);
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    int grid = 0;
+    if (int rc = launch_dims(ctx, lds, kernel, &grid)) return rc;
+
+    RenderArgs a{};
+    a.width = p->width;
+    a.height = p->height;
+    a.spt = spt;
+    a.tiles_x = (p->width + 7u) / 8u;
+    a.padded_pixels = a.tiles_x * ((p->height + 7u) / 8u) * 64u;
+    a.max_depth = p->max_depth;
+    a.sample_offset = p->sample_offset;
+    a.seed = p->seed;
+    // Slices are rendered in groups so that one launch stays within about 2^31 samples.
+    const uint64_t samples_per_slice = static_cast<uint64_t>(p->width) * p->height * std::max(spt, 1u);
+    uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (1ull << 31) / samples_per_slice));
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    for (uint32_t s0 = 0; s0 < n_sl; s0 += group) {
+        const uint32_t cnt = std::min(group, n_sl - s0);
+        a.n_items = static_cast<uint64_t>(cnt) * a.padded_pixels;
+        a.slice_first = p->slice_begin + s0;
+        a.slice_out = s0;
+        const uint64_t blocks_needed = (a.n_items + 255u) / 256u;
+        const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(grid), std::max<uint64_t>(blocks_needed, 1)));
+        if (count)
+            hipLaunchKernelGGL(k_render<true>, dim3(g), dim3(256), lds, stream, ctx->sc, a, static_cast<float*>(d_slice_sums),
+                               static_cast<unsigned long long*>(d_counters));
+        else
+            hipLaunchKernelGGL(k_render<false>, dim3(g), dim3(256), lds, stream, ctx->sc, a, static_cast<float*>(d_slice_sums),
+                               static_cast<unsigned long long*>(d_counters));
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    if (d_resolved || d_linear) {
+        const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
+        const uint32_t g = static_cast<uint32_t>((n_elems + 255u) / 256u);
+        hipLaunchKernelGGL(k_resolve, dim3(g), dim3(256), 0, stream, static_cast<const float*>(d_slice_sums), n_sl, n_elems,
+                           1.0f / static_cast<float>(spt), static_cast<float>(p->n_slices), static_cast<float*>(d_resolved),
+                           static_cast<float*>(d_linear));
+        HIP_TRY(hipGetLastError());
+    }
+    return RR_OK;
+}
+
+int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uint64_t n, void* hip_stream) {
+    if (!ctx || !d_resolved || !d_rgb8) return fail(RR_E_INVALID, "rr_cast_u8_device: NULL argument");
+    if (n == 0) return RR_OK;
+    if (int rc = set_device(ctx)) return rc;
+    const uint32_t g = static_cast<uint32_t>((n + 255u) / 256u);
+    hipLaunchKernelGGL(k_cast_u8, dim3(g), dim3(256), 0, static_cast<hipStream_t>(hip_stream), static_cast<const float*>(d_resolved),
+                       static_cast<uint8_t*>(d_rgb8), n);
+    HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_last_kernel_ms(rr_context* ctx, float* ms) {
+    if (!ctx || !ms) return fail(RR_E_INVALID, "rr_last_kernel_ms: NULL argument");
+    if (!ctx->timed) return fail(RR_E_INVALID, "rr_last_kernel_ms: nothing has been rendered yet");
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RR_OK;
+}
+
+int rr_render(rr_context* ctx, const rr_render_params* p, uint8_t* out_rgb8, float* out_resolved, float* out_linear,
+              float* out_slice_sums, rr_counters* out_counters) {
+    if (!ctx || !p) return fail(RR_E_INVALID, "rr_render: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_render: no scene uploaded");
+    if (p->slice_begin > p->slice_end || p->slice_end > p->n_slices || p->n_slices == 0 || p->width == 0 || p->height == 0)
+        return fail(RR_E_INVALID, "rr_render: bad image size or slice range");
+    if (int rc = set_device(ctx)) return rc;
+    const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
+    const uint32_t n_sl = p->slice_end - p->slice_begin;
+    float *d_sums = nullptr, *d_res = nullptr, *d_lin = nullptr;
+    uint8_t* d_u8 = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    auto cleanup = [&]() {
+        if (d_sums) (void)hipFree(d_sums);
+        if (d_res) (void)hipFree(d_res);
+        if (d_lin) (void)hipFree(d_lin);
+        if (d_u8) (void)hipFree(d_u8);
+        if (d_cnt) (void)hipFree(d_cnt);
+    };
+    auto hip_fail = [&](hipError_t e) {
+        cleanup();
+        return fail(RR_E_HIP, std::string("rr_render: ") + hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&d_sums, std::max<uint64_t>(1, n_sl) * n_elems * 4)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMalloc(&d_res, n_elems * 4)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMalloc(&d_lin, n_elems * 4)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMalloc(&d_u8, n_elems)) != hipSuccess) return hip_fail(e);
+    if ((e = hipMalloc(&d_cnt, sizeof(rr_counters))) != hipSuccess) return hip_fail(e);
+    if ((e = hipMemset(d_cnt, 0, sizeof(rr_counters))) != hipSuccess) return hip_fail(e);
+    int rc = rr_render_device(ctx, p, d_sums, d_res, d_lin, d_cnt, nullptr);
+    if (rc == RR_OK) rc = rr_cast_u8_device(ctx, d_res, d_u8, n_elems, nullptr);
+    if (rc != RR_OK) {
+        cleanup();
+        return rc;
+    }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e);
+    if (out_rgb8 && (e = hipMemcpy(out_rgb8, d_u8, n_elems, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_resolved && (e = hipMemcpy(out_resolved, d_res, n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_linear && (e = hipMemcpy(out_linear, d_lin, n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_slice_sums && n_sl && (e = hipMemcpy(out_slice_sums, d_sums, static_cast<uint64_t>(n_sl) * n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+        return hip_fail(e);
+    if (out_counters && (e = hipMemcpy(out_counters, d_cnt, sizeof(rr_counters), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    cleanup();
+    return RR_OK;
+}
+
+}  // extern "C"
