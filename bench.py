@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one full render pass of the workload (default: the Cornell box of
+src/main.rs:325-368 at 600x600, 1000 samples per pixel, depth 200) with the scene
+already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank renders its own N-th of the sample slices of ONE render_multi call
+with N x the samples (weak scaling: per-GPU work is fixed), and the per-GPU images are
+summed on rank 0 with one RCCL reduce inside the timed region.
+
+Rank 0 prints one JSON line.  `value` is whole-job Msamples/s; `roofline` prices the
+path-tracing kernel by its algorithmic bytes; `cpu_baseline` is the CPU oracle
+(oracle/librr_oracle.so, a C++ restatement of the reference: the Rust reference itself
+cannot be built here) timed on this box's host cores on a bounded sample of the same
+workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
+VALU_PEAK_TFLOPS = 157.3    # MI355X peak vector f32 (spec)
+
+WORKLOADS = {
+    # name: (scene, width, height, spp, depth)  — BASELINE.json configs[1..4]
+    "cornell": ("cornell", 600, 600, 1000, 200),
+    "suzanne": ("suzanne", 800, 800, 1000, 100),
+    "final": ("final", 800, 800, 10000, 50),
+    "spheres": ("spheres", 400, 225, 100, 50),
+}
+
+
+def host_threads():
+    n = len(os.sched_getaffinity(0))
+    env = os.environ.get("OMP_NUM_THREADS")
+    cap = int(env) if env and env.isdigit() else 16
+    return max(1, min(n, cap))
+
+
+def algorithmic_bytes_per_ray(c):
+    """Bytes the reference's algorithm has to read per ray: 32 B per box test, 16 B per sphere,
+    24 B per rect, 48 B per triangle, 16 B per instance/medium visit (counts measured by the
+    instrumented kernel; they are deterministic functions of scene and rays)."""
+    rays = max(1, c["rays"])
+    return (32.0 * c["box_tests"] + 16.0 * c["sphere_tests"] + 24.0 * c["rect_tests"] + 48.0 * c["tri_tests"] +
+            16.0 * c["inst_visits"]) / rays
+
+
+def flops_per_ray(c):
+    rays = max(1, c["rays"])
+    return (20.0 * c["box_tests"] + 30.0 * c["sphere_tests"] + 15.0 * c["rect_tests"] + 60.0 * c["tri_tests"]) / rays + 150.0
+
+
+def cpu_baseline(flat, width, height, depth, seed):
+    """Time the CPU oracle for roughly 10-20 s on this host: one full-image sample slice per thread."""
+    import oracle_lib as O
+    threads = host_threads()
+
+    def timed(spt):
+        p = O.make_params(width, height, threads * spt, n_slices=threads, max_depth=depth, seed=seed)
+        t0 = time.time()
+        r = O.render(flat, p, n_threads=threads, counters=True)
+        return time.time() - t0, r
+
+    spt = 1
+    dt, r = timed(spt)
+    rate = width * height * threads / dt
+    want = int(max(1, min(64, round(12.0 * rate / (width * height * threads)))))
+    if want > 1:
+        spt = want
+        dt, r = timed(spt)
+    samples = width * height * threads * spt
+    return {
+        "value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"{width}x{height}, {threads * spt} spp in {threads} slices, depth {depth}: {samples} samples in {dt:.1f} s",
+        "mrays_per_s": round(r["counters"]["rays"] / max(dt, 1e-9) / 1e6, 3),
+        "note": "C++ restatement of the reference (no per-hit Material clones, Box<PDF> allocations or atlas mutex), "
+                "so faster than the Rust binary would be: GPU/CPU ratios against it are conservative",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
+    ap.add_argument("--slices", type=int, default=8, help="sample slices per GPU (the reference's n_threads)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rust_raytracer_amd  # noqa: F401
+    from rust_raytracer_amd import device, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    scene_name, W, H, spp, depth = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    K = args.slices
+    builder, flat, _ = host.build_config_scene(scene_name, seed=args.seed)
+    ctx = device.Context(local_rank)
+    info = ctx.upload(flat)
+
+    # One render_multi call with world*K slices and world*spp samples; this rank renders slices
+    # [rank*K, (rank+1)*K): spp samples per pixel per GPU whatever the world size.
+    p = device.make_params(W, H, spp * world, n_slices=K * world, max_depth=depth, seed=args.seed,
+                           slice_begin=rank * K, slice_end=(rank + 1) * K)
+    spt = (spp * world) // (K * world)
+    dev = torch.device("cuda", local_rank)
+    slice_sums = torch.empty((K, H, W, 3), dtype=torch.float32, device=dev)
+    resolved = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    linear = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_device(p, slice_sums.data_ptr(), resolved.data_ptr(), linear.data_ptr(), counters.data_ptr(), stream)
+        if dist is not None:
+            dist.reduce(resolved, dst=0)
+            dist.reduce(linear, dst=0)
+        if rank == 0:
+            ctx.cast_u8_device(resolved.data_ptr(), rgb8.data_ptr(), resolved.numel(), stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    counters.zero_()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ctx.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = counters.clone()
+        dist.all_reduce(tot)
+        counts_all = tot.cpu().numpy()
+    else:
+        counts_all = counters.cpu().numpy()
+    counts_rank = counters.cpu().numpy()
+
+    if rank == 0:
+        samples_per_step = W * H * spt * K * world
+        total_samples = int(counts_all[0])
+        total_rays = int(counts_all[1])
+        assert total_samples == samples_per_step * args.steps, (total_samples, samples_per_step, args.steps)
+        value = total_samples / elapsed / 1e6
+
+        # per-ray work of the algorithm, from an instrumented pass outside the timed region
+        pc = device.make_params(W, H, K * world * 4, n_slices=K * world, max_depth=depth, seed=args.seed,
+                                slice_begin=0, slice_end=K, flags=1)
+        c2 = torch.zeros(8, dtype=torch.int64, device=dev)
+        ctx.render_device(pc, slice_sums.data_ptr(), None, None, c2.data_ptr(), stream)
+        torch.cuda.synchronize()
+        names = ["samples", "rays", "box_tests", "prim_tests", "inst_visits", "sphere_tests", "rect_tests", "tri_tests"]
+        cdict = dict(zip(names, [int(x) for x in c2.cpu().numpy()]))
+        bpr = algorithmic_bytes_per_ray(cdict)
+        fpr = flops_per_ray(cdict)
+        rays_per_launch = int(counts_rank[1]) / args.steps
+        samples_per_launch = int(counts_rank[0]) / args.steps
+        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {W}x{H}, {spp} spp per GPU in {K} slices per GPU, depth {depth}",
+                       "scene": scene_name, "width": W, "height": H, "spp_per_gpu": spp, "slices_per_gpu": K,
+                       "max_depth": depth, "parallelism": f"sample-slices x{world}", "seed": args.seed,
+                       "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
+            "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
+            "rays_per_sample": round(total_rays / max(1, total_samples), 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_render<false>", "kernel_ms": round(k_ms, 3),
+                         "algorithmic_bytes_per_ray": round(bpr, 2), "rays_per_launch": int(rays_per_launch),
+                         "per_ray": {k: round(cdict[k] / max(1, cdict["rays"]), 3) for k in names[2:]}},
+            "valu": {"flops_per_ray": round(fpr, 1), "achieved_tflops": round(fpr * rays_per_launch / (k_ms * 1e-3) / 1e12, 3),
+                     "peak_tflops": VALU_PEAK_TFLOPS,
+                     "frac": round(fpr * rays_per_launch / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5)},
+            "reference_published": {"msamples_per_s": 0.67, "source": "src/notes.txt:1-5 (600x600, 200 spp, depth 200, unknown CPU)"},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(flat, W, H, depth, args.seed)
+            out["speedup_vs_cpu_baseline"] = round(value / max(1e-9, out["cpu_baseline"]["value"]), 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -230,9 +230,11 @@ typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */
     uint64_t rays;        /* ray_color invocations with depth > 0 (one scene.intersect each) */
     uint64_t box_tests;   /* AABB::intersect calls                (RR_FLAG_COUNTERS)      */
-    uint64_t prim_tests;  /* sphere/rect/triangle intersector calls (RR_FLAG_COUNTERS)    */
+    uint64_t prim_tests;  /* all primitive intersector calls       (RR_FLAG_COUNTERS)     */
     uint64_t inst_visits; /* instance + medium visits              (RR_FLAG_COUNTERS)     */
-    uint64_t reserved[3];
+    uint64_t sphere_tests; /* of prim_tests: spheres and moving spheres                   */
+    uint64_t rect_tests;   /* of prim_tests: rects (cuboid sides included)                */
+    uint64_t tri_tests;    /* of prim_tests: triangles                                    */
 } rr_counters;
 
 typedef struct rr_hit {

@@ -318,7 +318,7 @@ bool hit_cuboid(Ctx& c, const rr_cuboid& cb, const Ray& r, float t_min, float t_
     float closest = t_max;
     for (uint32_t i = 0; i < 6; ++i) {
         Hit h;
-        if (c.cnt) c.cnt->prim_tests++;
+        if (c.cnt) c.cnt->prim_tests++, c.cnt->rect_tests++;
         if (hit_rect(c.s->rects[cb.first_rect + i], r, t_min, closest, h)) {
             any = true;
             closest = h.t;
@@ -426,7 +426,7 @@ bool hit_ref(Ctx& c, uint32_t ref, const Ray& r, float t_min, float t_max, Hit& 
     switch (RR_REF_TAG(ref)) {
         case RR_TAG_SPHERE: {
             const rr_sphere& sp = s.spheres[idx];
-            if (c.cnt) c.cnt->prim_tests++;
+            if (c.cnt) c.cnt->prim_tests++, c.cnt->sphere_tests++;
             if (!hit_sphere_at(from(sp.center), sp.radius, r, t_min, t_max, out, true)) return false;
             out.mat = sp.material;
             out.prim = static_cast<int32_t>(sp.prim_id);
@@ -434,7 +434,7 @@ bool hit_ref(Ctx& c, uint32_t ref, const Ray& r, float t_min, float t_max, Hit& 
         }
         case RR_TAG_MOVING_SPHERE: {
             const rr_moving_sphere& ms = s.moving_spheres[idx];
-            if (c.cnt) c.cnt->prim_tests++;
+            if (c.cnt) c.cnt->prim_tests++, c.cnt->sphere_tests++;
             V3 c0 = from(ms.center0), c1 = from(ms.center1);
             V3 center = c0 + (c1 - c0) * ((r.tm - ms.time0) / (ms.time1 - ms.time0));  // collider.rs:269-271
             if (!hit_sphere_at(center, ms.radius, r, t_min, t_max, out, false)) return false;
@@ -443,10 +443,10 @@ bool hit_ref(Ctx& c, uint32_t ref, const Ray& r, float t_min, float t_max, Hit& 
             return true;
         }
         case RR_TAG_RECT:
-            if (c.cnt) c.cnt->prim_tests++;
+            if (c.cnt) c.cnt->prim_tests++, c.cnt->rect_tests++;
             return hit_rect(s.rects[idx], r, t_min, t_max, out);
         case RR_TAG_TRIANGLE:
-            if (c.cnt) c.cnt->prim_tests++;
+            if (c.cnt) c.cnt->prim_tests++, c.cnt->tri_tests++;
             return hit_triangle(s.triangles[idx], r, out);
         case RR_TAG_CUBOID:
             return hit_cuboid(c, s.cuboids[idx], r, t_min, t_max, out);
@@ -681,6 +681,9 @@ void add_counters(rr_counters& a, const rr_counters& b) {
     a.rays += b.rays;
     a.box_tests += b.box_tests;
     a.prim_tests += b.prim_tests;
+    a.sphere_tests += b.sphere_tests;
+    a.rect_tests += b.rect_tests;
+    a.tri_tests += b.tri_tests;
     a.inst_visits += b.inst_visits;
 }
 

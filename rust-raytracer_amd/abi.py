@@ -123,10 +123,10 @@ class RenderParams(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("samples", u64), ("rays", u64), ("box_tests", u64), ("prim_tests", u64), ("inst_visits", u64),
-                ("reserved", u64 * 3)]
+                ("sphere_tests", u64), ("rect_tests", u64), ("tri_tests", u64)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k in ("samples", "rays", "box_tests", "prim_tests", "inst_visits")}
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class Hit(C.Structure):

@@ -79,7 +79,7 @@ struct DevScene {
 };
 
 struct Counts {
-    uint32_t rays, box_tests, prim_tests, inst_visits, samples;
+    uint32_t rays, box_tests, sphere_tests, rect_tests, tri_tests, inst_visits, samples;
 };
 
 // ------------------------------------------------------------------ math
@@ -389,7 +389,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                     node = NONE;
                 }
             } else if (tag == RR_TAG_SPHERE) {
-                if (COUNT) cnt.prim_tests++;
+                if (COUNT) cnt.sphere_tests++;
                 const float4 s = sc.sphere[idx];
                 float t;
                 if (test_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, tmax, t)) {
@@ -398,7 +398,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 }
                 node = NONE;
             } else if (tag == RR_TAG_TRIANGLE) {
-                if (COUNT) cnt.prim_tests++;
+                if (COUNT) cnt.tri_tests++;
                 float t;
                 if (test_triangle(sc, idx, o, d, t)) {
                     tmax = t;
@@ -406,7 +406,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 }
                 node = NONE;
             } else if (tag == RR_TAG_RECT) {
-                if (COUNT) cnt.prim_tests++;
+                if (COUNT) cnt.rect_tests++;
                 const float4 q0 = sc.rect[2 * idx], q1 = sc.rect[2 * idx + 1];
                 float t, ca, cb;
                 if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
@@ -418,7 +418,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 // six rects as a linear closest-hit list (collider.rs:428-430 → 751-772)
                 const uint32_t first = sc.cuboid[idx];
                 for (uint32_t i = 0; i < 6; ++i) {
-                    if (COUNT) cnt.prim_tests++;
+                    if (COUNT) cnt.rect_tests++;
                     const float4 q0 = sc.rect[2 * (first + i)], q1 = sc.rect[2 * (first + i) + 1];
                     float t, ca, cb;
                     if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
@@ -428,7 +428,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 }
                 node = NONE;
             } else if (tag == RR_TAG_MOVING_SPHERE) {
-                if (COUNT) cnt.prim_tests++;
+                if (COUNT) cnt.sphere_tests++;
                 const float4 a = sc.msphere[3 * idx], b = sc.msphere[3 * idx + 1], c = sc.msphere[3 * idx + 2];
                 float t;
                 if (test_sphere(msphere_center(a, b, time), c.x, o, d, tmin, tmax, t)) {

@@ -44,9 +44,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* counters) {
     if (!counters) return;
-    unsigned long long v[5] = {c.samples, c.rays, c.box_tests, c.prim_tests, c.inst_visits};
+    unsigned long long v[8] = {c.samples, c.rays, c.box_tests, (unsigned long long)c.sphere_tests + c.rect_tests + c.tri_tests, c.inst_visits, c.sphere_tests, c.rect_tests, c.tri_tests};
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 8; ++i) {
         unsigned long long s = wave_sum(v[i]);
         if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&counters[i], s);
     }
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, RenderArgs a, float
     const uint64_t item_stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
 
-    Counts cnt = {0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
     bool have_item = false, path_active = false;
     uint32_t px = 0, py = 0, sl = 0, s = 0;
     f3 acc = mk3(0.f, 0.f, 0.f);
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, c
     const float time = r[6];
     Rng g;
     g.start(seed, i, 0, 0);
-    Counts cnt = {0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
     float t;
     uint32_t ref;
     traverse<false>(sc, o, d, time, t_min, t_max, g, stk, blockDim.x, t, ref, cnt);
