@@ -1,0 +1,228 @@
+"""Scene descriptions shared by the golden-fixture generator and the parity tests.
+
+Each scene function takes an adapter `A` with the reference's constructor names and returns
+(objects, camera_args).  Two adapters exist: PyAdapter builds the tree for oracle/pyoracle.py
+(the independent Python restatement), HostAdapter builds it through the host library
+(librr_host.so) whose flattening the C++ oracle and the GPU read.  The fixtures under
+tests/golden/ hold what pyoracle computed; the tests rebuild the same scene through the
+host library and compare.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+class PyAdapter:
+    def __init__(self, seed):
+        import pyoracle as P
+        self.P = P
+        self.rng = P.PCG32(seed)
+
+    def sphere(self, c, r):
+        return self.P.sphere(c, r)
+
+    def moving_sphere(self, c0, c1, t0, t1, r):
+        return self.P.moving_sphere(c0, c1, t0, t1, r)
+
+    def xyrect(self, *a):
+        return self.P.xyrect(*a)
+
+    def xzrect(self, *a):
+        return self.P.xzrect(*a)
+
+    def yzrect(self, *a):
+        return self.P.yzrect(*a)
+
+    def cuboid(self, p0, p1):
+        return self.P.cuboid(p0, p1)
+
+    def medium(self, g, density):
+        return self.P.constant_medium(g, density)
+
+    def translate(self, g, d):
+        return self.P.translate(g, d)
+
+    def rotate(self, g, axis, angle):
+        return self.P.rotate(g, axis, angle)
+
+    def triangle(self, p0, p1, p2):
+        return self.P.triangle(p0, p1, p2)
+
+    def bvh(self, items):
+        return self.P.bvh_node(items, 0.0, 1.0, self.rng)
+
+    def bvh_explicit(self, left, right, axis, box):
+        b = None if box is None else (self.P.v3(*box[0]), self.P.v3(*box[1]))
+        return self.P.Geometry("bvh", left=left, right=right, box=b, axis=axis)
+
+    def list(self, items):
+        return self.P.collider_list(items)
+
+
+class HostAdapter:
+    """Same constructors through rust_raytracer_amd.host.SceneBuilder (all geometry white Lambertian)."""
+
+    def __init__(self, seed):
+        import rust_raytracer_amd  # noqa: F401
+        from rust_raytracer_amd import host
+        self.b = host.SceneBuilder(seed)
+        self.m = self.b.lambertian(self.b.solid_color((0.73, 0.73, 0.73)))
+
+    def sphere(self, c, r):
+        return self.b.sphere(c, r, self.m)
+
+    def moving_sphere(self, c0, c1, t0, t1, r):
+        return self.b.moving_sphere(c0, c1, t0, t1, r, self.m)
+
+    def xyrect(self, *a):
+        return self.b.xyrect(*a, self.m)
+
+    def xzrect(self, *a):
+        return self.b.xzrect(*a, self.m)
+
+    def yzrect(self, *a):
+        return self.b.yzrect(*a, self.m)
+
+    def cuboid(self, p0, p1):
+        return self.b.cuboid(p0, p1, self.m)
+
+    def medium(self, g, density):
+        return self.b.constant_medium(g, density, (1, 1, 1))
+
+    def translate(self, g, d):
+        return self.b.instance_translation(g, d)
+
+    def rotate(self, g, axis, angle):
+        return self.b.instance_rotation(g, axis, angle)
+
+    def triangle(self, p0, p1, p2):
+        return self.b.triangle(p0, p1, p2, self.m)
+
+    def bvh(self, items):
+        return self.b.bvh_node(items, 0.0, 1.0)
+
+    def bvh_explicit(self, left, right, axis, box):
+        return self.b.bvh_node_explicit(left, right, axis, box)
+
+    def list(self, items):
+        return self.b.collider_list(items)
+
+
+CORNELL_CAM = dict(look_from=(278, 278, -800), look_at=(278, 278, 0), vup=(0, 1, 0), vfov=40.0, aperture=0.0,
+                   focus_dist=10.0, aspect=1.0)
+BOOK_CAM = dict(look_from=(13, 2, 3), look_at=(0, 0, 0), vup=(0, 1, 0), vfov=20.0, aperture=0.0, focus_dist=10.0,
+                aspect=1.5)
+
+
+def cornell(A):  # src/main.rs:357-365
+    objs = [A.yzrect(0, 555, 0, 555, 555), A.yzrect(0, 555, 0, 555, 0), A.xzrect(213, 343, 227, 332, 554),
+            A.xzrect(0, 555, 0, 555, 0), A.xzrect(0, 555, 0, 555, 555), A.xyrect(0, 555, 0, 555, 555),
+            A.translate(A.rotate(A.cuboid((0, 0, 0), (165, 330, 165)), 1, 15.0), (265, 0, 295)),
+            A.translate(A.rotate(A.cuboid((0, 0, 0), (165, 165, 165)), 1, -18.0), (130, 0, 65))]
+    return objs, CORNELL_CAM
+
+
+def sphere_bvh(A):
+    """A ground sphere, then one BVH over 61 static spheres, a hollow (negative-radius) one and two moving ones."""
+    rs = np.random.RandomState(5)
+    items = []
+    for _ in range(61):
+        c = rs.uniform(-5, 5, 3).astype(np.float32)
+        c[1] = np.float32(0.2 + rs.uniform(0, 1.5))
+        items.append(A.sphere(tuple(c), float(np.float32(rs.uniform(0.15, 0.6)))))
+    items.append(A.sphere((0.0, 1.0, 0.0), -0.8))
+    items.append(A.moving_sphere((2.0, 0.5, 1.0), (2.0, 1.2, 1.0), 0.0, 1.0, 0.4))
+    items.append(A.moving_sphere((-2.0, 0.5, -1.0), (-1.5, 0.5, -1.0), 0.0, 1.0, 0.3))
+    return [A.sphere((0, -1000, 0), 1000.0), A.bvh(items)], BOOK_CAM
+
+
+def hand_tree(A):
+    """Three primitives under hand-built BVH nodes: exercises the first-child-miss branch that re-tests
+    `left` (collider.rs:555-561), span-1 leaves (same node on both sides), a node without a box, and a
+    triangle that ignores t_max (collider.rs:627)."""
+    s_near = A.sphere((0.0, 0.0, -2.0), 0.5)
+    s_right = A.sphere((1.5, 0.0, -3.0), 0.5)
+    tri_far = A.triangle((-3.0, -3.0, -6.0), (3.0, -3.0, -6.0), (0.0, 3.0, -6.0))
+    leaf = A.bvh_explicit(s_right, s_right, 1, ((1.0, -0.5, -3.5), (2.0, 0.5, -2.5)))
+    inner = A.bvh_explicit(s_near, leaf, 0, ((-0.5, -0.5, -3.5), (2.0, 0.5, -1.5)))
+    top = A.bvh_explicit(inner, tri_far, 1, None)
+    cam = dict(look_from=(0, 0, 2), look_at=(0, 0, -3), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0, aspect=1.0)
+    return [top], cam
+
+
+def tri_mesh(A):
+    """A jittered 6x6 grid of triangle pairs under translate(rotZ(rotY(bvh))) — the nesting of
+    cornell_pedestal (main.rs:461) — inside the Cornell walls."""
+    rs = np.random.RandomState(9)
+    n = 6
+    pts = np.zeros((n + 1, n + 1, 3), dtype=np.float32)
+    for j in range(n + 1):
+        for i in range(n + 1):
+            pts[j, i] = (i * 30.0 - 90.0 + rs.uniform(-4, 4), 40.0 * np.sin(i * 0.9) * np.cos(j * 0.7) + rs.uniform(-4, 4),
+                         j * 30.0 - 90.0 + rs.uniform(-4, 4))
+    tris = []
+    for j in range(n):
+        for i in range(n):
+            tris.append(A.triangle(tuple(pts[j, i]), tuple(pts[j + 1, i]), tuple(pts[j, i + 1])))
+            tris.append(A.triangle(tuple(pts[j, i + 1]), tuple(pts[j + 1, i]), tuple(pts[j + 1, i + 1])))
+    mesh = A.translate(A.rotate(A.rotate(A.bvh(tris), 1, 145.0), 2, -30.0), (270, 200, 178))
+    objs = [A.yzrect(0, 555, 0, 555, 555), A.yzrect(0, 555, 0, 555, 0), A.xzrect(0, 555, 0, 555, 0),
+            A.xzrect(0, 555, 0, 555, 555), A.xyrect(0, 555, 0, 555, 555), mesh]
+    return objs, CORNELL_CAM
+
+
+def media(A):
+    """Constant media: a sphere of smoke, smoke inside translate(rotate(cuboid)) as in cornell_smoke
+    (main.rs:410), and a thin global medium as in final_scene (main.rs:522-523)."""
+    objs = [A.xzrect(0, 555, 0, 555, 0), A.xyrect(0, 555, 0, 555, 555),
+            A.medium(A.sphere((360, 150, 145), 70.0), 0.02),
+            A.medium(A.translate(A.rotate(A.cuboid((0, 0, 0), (165, 330, 165)), 1, 15.0), (265, 0, 295)), 0.01),
+            A.medium(A.sphere((0, 0, 0), 5000.0), 0.0005),
+            A.sphere((150, 100, 300), 60.0)]
+    return objs, CORNELL_CAM
+
+
+def cuboid_bvh(A):
+    """A 4x4 field of cuboids of different heights under one BVH (final_scene's floor, main.rs:498-511),
+    with a list of two spheres as one more top-level object."""
+    rs = np.random.RandomState(3)
+    boxes = []
+    for i in range(4):
+        for j in range(4):
+            x0, z0 = -200.0 + i * 100.0, -200.0 + j * 100.0
+            boxes.append(A.cuboid((x0, 0.0, z0), (x0 + 100.0, float(np.float32(rs.uniform(1, 101))), z0 + 100.0)))
+    objs = [A.bvh(boxes), A.list([A.sphere((0, 150, 0), 40.0), A.sphere((60, 130, 40), 30.0)])]
+    cam = dict(look_from=(478, 278, -600), look_at=(0, 50, 0), vup=(0, 1, 0), vfov=40.0, aperture=0.0, focus_dist=10.0, aspect=1.0)
+    return objs, cam
+
+
+SCENES = {
+    # name: (function, bvh seed, rays per side)
+    "cornell": (cornell, 1, 32),
+    "sphere_bvh": (sphere_bvh, 11, 28),
+    "hand_tree": (hand_tree, 1, 24),
+    "tri_mesh": (tri_mesh, 4, 28),
+    "media": (media, 1, 24),
+    "cuboid_bvh": (cuboid_bvh, 6, 24),
+}
+MEDIA_SEED = 77  # seed of the Philox streams that feed the constant media in the fixtures
+
+
+def build_host(name):
+    """→ (adapter, FlatScene) of scene `name` built through the host library."""
+    fn, seed, _ = SCENES[name]
+    A = HostAdapter(seed)
+    objs, cam = fn(A)
+    for g in objs:
+        A.b.add(g)
+    A.b.set_camera(cam["look_from"], cam["look_at"], cam["vup"], cam["vfov"], cam["aperture"], cam["focus_dist"],
+                   cam["aspect"], 0.0, 1.0)
+    return A, A.b.flatten()

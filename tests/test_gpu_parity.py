@@ -1,0 +1,235 @@
+"""Parity of the HIP path (through the C ABI, on a real MI355X) with the CPU oracle and the golden fixtures.
+
+Bars: primitive ids exact; t, point and normals within 1e-5 relative (bit-exact where no
+transcendental is involved); per-slice pixel sums of whole renders within 1e-3 relative for at
+least 98 % of the channels (paths share their random numbers with the oracle, so the remainder are
+paths that a last-bit difference in sin/cos/log10 sent somewhere else) and image means within 1 %.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rust_raytracer_amd  # noqa: F401
+from rust_raytracer_amd import abi, device, host
+import golden_scenes as G
+import oracle_lib as O
+from test_golden_cpu import compare_hits
+
+pytestmark = pytest.mark.gpu
+
+CONFIG_SCENES = {}
+
+
+def config_scene(name):
+    if name not in CONFIG_SCENES:
+        CONFIG_SCENES[name] = host.build_config_scene(name)
+    return CONFIG_SCENES[name]
+
+
+# ------------------------------------------------------------ primary hits
+@pytest.mark.parametrize("name", sorted(G.SCENES))
+def test_primary_hits_match_golden_fixtures(gpu_ctx, name):
+    fx = np.load(f"{G.GOLDEN_DIR}/hits_{name}.npz")
+    A, flat = G.build_host(name)
+    gpu_ctx.upload(flat)
+    got = gpu_ctx.primary_hits(fx["rays"], seed=int(fx["media_seed"]))
+    compare_hits(got, fx["hits"], exact_t=(name != "media"))
+
+
+@pytest.mark.parametrize("name,side", [("cornell", 96), ("spheres", 96), ("suzanne", 96), ("final", 96)])
+def test_primary_hits_match_oracle_on_benchmark_scenes(gpu_ctx, name, side):
+    """Camera rays of the benchmark scenes (thin lens, shutter time and all): ids exact, t and normals 1e-5."""
+    b, flat, d = config_scene(name)
+    gpu_ctx.upload(flat)
+    W, H = d["width"], d["height"]
+    p = O.make_params(W, H, 4, n_slices=1, seed=11)
+    pixels = [(int(i * (W - 1) / (side - 1)), int(j * (H - 1) / (side - 1))) for j in range(side) for i in range(side)]
+    rays = O.camera_rays(flat, p, pixels, sample=2)
+    want = O.primary_hits(flat, rays, seed=5)
+    got = gpu_ctx.primary_hits(rays, seed=5)
+    has_media = flat.n_media > 0
+    compare_hits(got, want, exact_t=not has_media)
+    assert np.array_equal(got["material"], want["material"])
+    assert (want["prim_id"] >= 0).mean() > 0.5
+
+
+def test_primary_hits_honour_the_t_range(gpu_ctx):
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    rays = np.array([[278, 278, -800, 0, 0, 1, 0]], dtype=np.float32)
+    for t_min, t_max in [(0.001, 3.4e38), (0.001, 900.0), (1200.0, 3.4e38), (1400.0, 3.4e38)]:
+        got, want = gpu_ctx.primary_hits(rays, t_min, t_max), O.primary_hits(flat, rays, t_min, t_max)
+        assert got["prim_id"][0] == want["prim_id"][0] and got["t"][0] == want["t"][0]
+    assert gpu_ctx.primary_hits(rays, 1400.0, 3.4e38)["prim_id"][0] == -1
+    assert len(gpu_ctx.primary_hits(np.zeros((0, 7), dtype=np.float32))) == 0
+
+
+# ------------------------------------------------------------ whole renders
+def render_both(ctx, flat, p, n_threads=16):
+    ctx.upload(flat)
+    return ctx.render(p), O.render(flat, p, n_threads=n_threads, counters=True)
+
+
+def assert_render_parity(got, want, min_close=0.98, mean_tol=0.01):
+    a, c = got["slice_sums"], want["slice_sums"]
+    nan_a, nan_c = np.isnan(a), np.isnan(c)
+    assert (nan_a == nan_c).mean() > 0.995, "NaN pixels (zeroed per slice by render.rs:106-108) disagree"
+    both = ~nan_a & ~nan_c
+    close = np.isclose(a[both], c[both], rtol=1e-3, atol=1e-5)
+    assert close.mean() >= min_close, f"only {close.mean():.4f} of the per-slice channel sums agree"
+    ma, mc = float(a[both].mean()), float(c[both].mean())
+    assert abs(ma - mc) <= mean_tol * max(abs(mc), 1e-6), (ma, mc)
+    # 8-bit images: identical almost everywhere, never far apart
+    d8 = np.abs(got["rgb8"].astype(np.int32) - want["rgb8"].astype(np.int32))
+    assert (d8 <= 1).mean() > 0.97 and np.allclose(got["linear"][both.all(axis=0)], want["linear"][both.all(axis=0)], rtol=0.5, atol=1.0)
+
+
+def test_cornell_render_matches_oracle(gpu_ctx):
+    b, flat, _ = config_scene("cornell")
+    p = device.make_params(96, 96, 16, n_slices=4, max_depth=200, seed=21)
+    got, want = render_both(gpu_ctx, flat, p)
+    assert_render_parity(got, want)
+    assert got["counters"]["samples"] == want["counters"]["samples"] == 96 * 96 * 16
+    assert abs(got["counters"]["rays"] - want["counters"]["rays"]) <= 2e-3 * want["counters"]["rays"]
+
+
+def test_random_spheres_render_matches_oracle(gpu_ctx):
+    """Sky-lit scene with glossy and dielectric spheres and an empty lights list: exercises the zero
+    scattering pdf of non-Lambertian materials and the NaN samples of pdf 0 (render.rs:34)."""
+    b, flat, _ = config_scene("spheres")
+    p = device.make_params(80, 45, 16, n_slices=4, max_depth=50, seed=2)
+    got, want = render_both(gpu_ctx, flat, p)
+    assert np.isnan(want["slice_sums"]).any(), "this scene is expected to produce NaN samples"
+    assert_render_parity(got, want)
+
+
+def test_suzanne_render_matches_oracle(gpu_ctx):
+    b, flat, _ = config_scene("suzanne")
+    p = device.make_params(64, 64, 8, n_slices=2, max_depth=100, seed=4)
+    got, want = render_both(gpu_ctx, flat, p)
+    assert_render_parity(got, want)
+
+
+def test_final_scene_render_matches_oracle(gpu_ctx):
+    """Media, Perlin and image textures, moving sphere, instanced sphere BVH, cuboid BVH."""
+    b, flat, _ = config_scene("final")
+    p = device.make_params(64, 64, 8, n_slices=2, max_depth=50, seed=8)
+    got, want = render_both(gpu_ctx, flat, p)
+    assert_render_parity(got, want, min_close=0.97)
+
+
+def test_intersection_counters_match_oracle(gpu_ctx):
+    """The instrumented kernel counts the same box and primitive tests as the recursive oracle."""
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    p = device.make_params(48, 48, 8, n_slices=2, max_depth=50, seed=3, flags=abi.FLAG_COUNTERS)
+    got = gpu_ctx.render(p)["counters"]
+    assert got["rect_tests"] == 18 * got["rays"] and got["inst_visits"] == 4 * got["rays"] and got["box_tests"] == 0
+    assert got["prim_tests"] == got["rect_tests"] + got["sphere_tests"] + got["tri_tests"]
+    b, flat, _ = config_scene("suzanne")
+    gpu_ctx.upload(flat)
+    p = device.make_params(32, 32, 4, n_slices=2, max_depth=20, seed=3, flags=abi.FLAG_COUNTERS)
+    got = gpu_ctx.render(p)["counters"]
+    want = O.render(flat, p, n_threads=8, counters=True)["counters"]
+    for k in ("rays", "box_tests", "tri_tests", "rect_tests", "inst_visits"):
+        assert abs(got[k] - want[k]) <= 5e-3 * want[k], (k, got[k], want[k])
+
+
+# --------------------------------------------------- size-independent properties
+def test_render_is_deterministic_and_slices_compose(gpu_ctx):
+    """Bit-identical reruns; rendering slice ranges separately equals rendering them together; a
+    sample_offset render equals the matching slices of a larger render (how GPUs split one image)."""
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    K, spt, W, H = 4, 3, 120, 72
+    full = gpu_ctx.render(device.make_params(W, H, K * spt, n_slices=K, max_depth=30, seed=5))
+    again = gpu_ctx.render(device.make_params(W, H, K * spt, n_slices=K, max_depth=30, seed=5))
+    assert np.array_equal(full["slice_sums"], again["slice_sums"], equal_nan=True)
+    lo = gpu_ctx.render(device.make_params(W, H, K * spt, n_slices=K, max_depth=30, seed=5, slice_begin=0, slice_end=1))
+    hi = gpu_ctx.render(device.make_params(W, H, K * spt, n_slices=K, max_depth=30, seed=5, slice_begin=1, slice_end=4))
+    assert np.array_equal(np.concatenate([lo["slice_sums"], hi["slice_sums"]]), full["slice_sums"], equal_nan=True)
+    assert np.allclose(lo["resolved"] + hi["resolved"], full["resolved"], rtol=1e-6)
+    assert lo["counters"]["rays"] + hi["counters"]["rays"] == full["counters"]["rays"]
+    half = K // 2
+    off = gpu_ctx.render(device.make_params(W, H, half * spt, n_slices=half, max_depth=30, seed=5, sample_offset=half * spt))
+    assert np.array_equal(off["slice_sums"], full["slice_sums"][half:], equal_nan=True)
+    other_seed = gpu_ctx.render(device.make_params(W, H, K * spt, n_slices=K, max_depth=30, seed=6))
+    assert not np.array_equal(other_seed["slice_sums"], full["slice_sums"])
+
+
+def test_full_size_cornell_configuration(gpu_ctx):
+    """BASELINE configuration 2 at full size (600x600, 1000 spp, depth 200): every sample is traced,
+    nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    p = device.make_params(600, 600, 1000, n_slices=8, max_depth=200, seed=1)
+    r = gpu_ctx.render(p, slice_sums=False)
+    assert r["counters"]["samples"] == 600 * 600 * 1000
+    assert 2.5 < r["counters"]["rays"] / r["counters"]["samples"] < 3.5
+    assert np.isfinite(r["linear"]).all() and r["rgb8"].max() == 255
+    ref = O.render(flat, O.make_params(600, 600, 16, n_slices=8, max_depth=200, seed=77), n_threads=16)
+    m_gpu, m_ref = r["linear"].mean() / 1000.0, ref["linear"].mean() / 16.0
+    assert abs(m_gpu - m_ref) < 0.01 * m_ref, (m_gpu, m_ref)
+    # per-pixel: the 1000-spp image is the converged version of the 16-spp one
+    rmse = np.sqrt(np.mean((r["linear"] / 1000.0 - ref["linear"] / 16.0) ** 2))
+    assert rmse < 0.35, rmse
+
+
+# ------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("W,H", [(2, 2), (37, 21), (8, 8), (65, 9)])
+def test_odd_image_sizes(gpu_ctx, W, H):
+    b, flat, _ = config_scene("cornell")
+    p = device.make_params(W, H, 4, n_slices=2, max_depth=20, seed=13)
+    got, want = render_both(gpu_ctx, flat, p)
+    assert got["slice_sums"].shape == (2, H, W, 3)
+    assert_render_parity(got, want, min_close=0.95, mean_tol=0.05)
+
+
+def test_degenerate_parameters(gpu_ctx):
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    r = gpu_ctx.render(device.make_params(16, 16, 3, n_slices=4, max_depth=10))        # 3 / 4 = 0 samples per slice
+    assert (r["slice_sums"] == 0).all() and np.isnan(r["resolved"]).all() and (r["rgb8"] == 0).all()
+    r = gpu_ctx.render(device.make_params(16, 16, 4, n_slices=2, max_depth=0))         # depth 0: black, no rays
+    assert (r["slice_sums"] == 0).all() and r["counters"]["rays"] == 0 and r["counters"]["samples"] == 16 * 16 * 4
+    r = gpu_ctx.render(device.make_params(16, 16, 4, n_slices=2, max_depth=5, slice_begin=1, slice_end=1))   # empty range
+    assert r["slice_sums"].shape[0] == 0 and r["counters"]["samples"] == 0
+    # empty scene: every sample returns the background (render.rs:39)
+    e = host.SceneBuilder(1)
+    e.set_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, 0.0, 1.0, 1.0)
+    e.set_background((0.25, 0.5, 1.0))
+    gpu_ctx.upload(e.flatten())
+    r = gpu_ctx.render(device.make_params(8, 8, 6, n_slices=2, max_depth=5))
+    assert np.array_equal(r["slice_sums"], np.broadcast_to(np.float32([0.75, 1.5, 3.0]), (2, 8, 8, 3)))
+    assert list(r["rgb8"][0, 0]) == [128, 181, 255]   # 2 slices x 256 * sqrt(c) / 2, saturating cast
+
+
+def test_errors_are_reported_not_swallowed(gpu_ctx):
+    fresh = device.Context(0)
+    with pytest.raises(device.DeviceError, match="no scene"):
+        fresh.render(device.make_params(8, 8, 4))
+    b, flat, _ = host.build_config_scene("cornell")
+    bad = abi.FlatScene.from_buffer_copy(flat)
+    refs = (C.c_uint32 * flat.n_child_refs)(*[flat.child_refs[i] for i in range(flat.n_child_refs)])
+    refs[0] = abi.ref(abi.TAG_SPHERE, 5)             # no spheres in this scene
+    bad.child_refs = C.cast(refs, C.POINTER(C.c_uint32))
+    with pytest.raises(device.DeviceError, match="out of range"):
+        fresh.upload(bad)
+    refs[0] = flat.root                               # the root list inside itself: a cycle
+    with pytest.raises(device.DeviceError, match="tree|twice|deeper"):
+        fresh.upload(bad)
+    with pytest.raises(device.DeviceError):
+        fresh.render(device.make_params(8, 8, 4))     # the failed uploads left no scene behind
+    fresh.upload(flat)
+    with pytest.raises(device.DeviceError, match="slice"):
+        fresh.render(device.make_params(8, 8, 4, n_slices=2, slice_begin=1, slice_end=3))
+    d = host.SceneBuilder(1)
+    m = d.lambertian(d.solid_color((1, 1, 1)))
+    g = d.sphere((0, 0, 0), 1.0, m)
+    for _ in range(9):
+        g = d.instance_translation(g, (1, 0, 0))
+    d.add(g)
+    with pytest.raises(device.DeviceError, match="nested deeper"):
+        fresh.upload(d.flatten())
+    fresh.close()
