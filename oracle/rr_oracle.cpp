@@ -31,7 +31,11 @@
 // a u32 becomes an f32 on the 2^-23 grid of [0,1) (rand 0.8.5's gen_range(0f32..1f32)).
 // The camera draws of one sample use bounce 0xFFFFFFFF; ray_color call number b
 // (b = 0 for the camera ray) uses bounce b, drawing in the reference's own order:
-// traversal (constant media), then scatter, then mixture.generate.
+// traversal (constant media), then scatter, then mixture.generate.  One rule departs
+// from "draw wherever the reference draws": a draw whose value cannot influence the
+// result (the scattered direction that render.rs:32 overwrites, the lens sample of an
+// aperture-0 camera) is not taken.  Streams are counter-based and draws independent, so
+// this changes no distribution; it only keeps the streams short.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -556,9 +560,10 @@ float reflectance(float cosin, float ref_idx) {  // material.rs:116-120
 bool scatter(const rr_flat_scene& s, const rr_material& m, const Ray& r_in, const Hit& rec, Philox& g, V3& attenuation) {
     switch (m.type) {
         case RR_MAT_LAMBERTIAN: {
-            ONB uvw = ONB::from_w(rec.n);
-            V3 dir = uvw.local(random_cosine_direction(g));
-            (void)dir;
+            // material.rs:85-92 draws a cosine direction here that render.rs:32 then overwrites.  Draws
+            // that can influence neither the return value nor the attenuation are not taken from the
+            // counter-based stream (they are independent of every other draw, so the distribution of
+            // the result is unchanged); the same holds for the dielectric coin and the isotropic direction.
             attenuation = texture_color(s, m.texture, rec.u, rec.v, rec.p);
             return true;
         }
@@ -569,22 +574,12 @@ bool scatter(const rr_flat_scene& s, const rr_material& m, const Ray& r_in, cons
             return dot(sd, rec.n) > 0.0f;
         }
         case RR_MAT_DIELECTRIC: {
+            // material.rs:128-148: reflect or refract by Schlick's approximation — into a direction that is
+            // discarded; what remains is attenuation 1 and `true`
             attenuation = mk(1, 1, 1);
-            float ratio = rec.front ? 1.0f / m.param : m.param;
-            V3 ud = unit(r_in.d);
-            float cos_theta = std::fmin(dot(neg(ud), rec.n), 1.0f);
-            float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
-            bool cannot_refract = ratio * sin_theta > 1.0f;
-            // `||` short-circuits: random() is drawn only when refraction is possible
-            if (cannot_refract || reflectance(cos_theta, ratio) > g.random()) {
-                (void)reflect(ud, rec.n);
-            } else {
-                (void)refract(ud, rec.n, ratio);
-            }
             return true;
         }
-        case RR_MAT_ISOTROPIC: {
-            (void)random_in_unit_sphere(g);
+        case RR_MAT_ISOTROPIC: {  // material.rs:150-154
             attenuation = texture_color(s, m.texture, rec.u, rec.v, rec.p);
             return true;
         }
@@ -647,7 +642,8 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
 }
 
 Ray camera_ray(const rr_camera& cam, float u, float v, Philox& g) {  // camera.rs:76-84
-    V3 rd = random_in_unit_disk(g) * cam.lens_radius;
+    // with aperture 0 the lens sample is multiplied by zero (camera.rs:77): not drawn
+    V3 rd = (cam.lens_radius != 0.0f ? random_in_unit_disk(g) : mk(0, 0, 0)) * cam.lens_radius;
     V3 offset = from(cam.u) * rd.x + from(cam.v) * rd.y;
     V3 origin = from(cam.origin);
     Ray r;
@@ -715,6 +711,19 @@ void rro_texture_color(const rr_flat_scene* s, uint32_t tex, float u, float v, c
     out[1] = c.y;
     out[2] = c.z;
 }
+
+// vec3.rs:268-277 and material.rs:116-120.  The reference evaluates these inside scatter_glossy /
+// scatter_dielectric; the dielectric's result is discarded by render.rs:32, so nothing on the
+// rendering path reads refract or reflectance — they are kept restated and testable here.
+void rro_reflect(const float v[3], const float n[3], float out[3]) {
+    V3 r = reflect(from(v), from(n));
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+void rro_refract(const float uv[3], const float n[3], float etai_over_etat, float out[3]) {
+    V3 r = refract(from(uv), from(n), etai_over_etat);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+float rro_reflectance(float cosin, float ref_idx) { return reflectance(cosin, ref_idx); }
 
 float rro_light_pdf_value(const rr_flat_scene* s, const float origin[3], const float v[3]) {
     return light_pdf_value(s->light, from(origin), from(v));

@@ -154,16 +154,6 @@ struct Rng {
         }
     }
 };
-// Advance past draws whose values nobody reads.  next_u32 only refills when n&3 == 0,
-// so a skip that lands inside a block that is not the buffered one refills here.
-__device__ __forceinline__ void rng_skip(Rng& g, uint32_t count) {
-    uint32_t before = g.n >> 2;
-    bool had_block = (g.n & 3u) != 0;  // current block is buffered only if partially consumed
-    g.n += count;
-    uint32_t after = g.n >> 2;
-    if ((g.n & 3u) != 0 && (after != before || !had_block)) g.refill();
-}
-
 constexpr uint32_t CAMERA_BOUNCE = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------- instances
@@ -360,12 +350,12 @@ __device__ __forceinline__ f3 msphere_center(float4 a, float4 b, float time) {  
 //
 // stk addresses this lane's stack: word w lives at stk[w * stride].
 template <bool COUNT>
-__device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, Rng& rng,
-                                         uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
-    f3 o = wo, d = wd;
-    uint32_t cur = NONE;
+__device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 wo, f3 wd, f3 o, f3 d, float time, float tmin,
+                                        float& tmax_io, uint32_t& cur_io, Rng& rng, uint32_t* stk, uint32_t stride, Counts& cnt) {
+    float tmax = tmax_io;
+    uint32_t cur = cur_io;
     uint32_t sp = 0;
-    uint32_t node = sc.root;
+    uint32_t node = start;
     for (;;) {
         // ------------------------------------------------ evaluate `node`
         if (node != NONE) {
@@ -535,6 +525,139 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 }
             }
         }
+    }
+    tmax_io = tmax;
+    cur_io = cur;
+}
+
+// ------------------------------------------------- wave-uniform traversal
+// Lists, instances, cuboids and media are visited by EVERY ray that reaches them: only
+// BVH nodes decide anything from the ray.  The part of the tree above the BVHs is
+// therefore walked once per wave with scalar control flow and scalar loads (the record
+// of the node all 64 lanes are testing sits in SGPRs), and only BVH subtrees — or
+// shapes this layer does not special-case — run on the per-lane machine above.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Primitive or cuboid named by the wave-uniform ref `n`, against the lanes' rays.
+template <bool COUNT>
+__device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, f3 d, float time, float tmin, float& tmax,
+                                          uint32_t& cur, Counts& cnt) {
+    const uint32_t tag = dtag(n), idx = didx(n);
+    if (tag == RR_TAG_RECT) {
+        if (COUNT) cnt.rect_tests++;
+        const float4 q0 = sc.rect[2 * idx], q1 = sc.rect[2 * idx + 1];
+        float t, ca, cb;
+        if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
+            tmax = t;
+            cur = n;
+        }
+    } else if (tag == RR_TAG_CUBOID) {  // collider.rs:428-430 → 751-772
+        const uint32_t first = uni(sc.cuboid[idx]);
+#pragma unroll
+        for (uint32_t i = 0; i < 6; ++i) {
+            if (COUNT) cnt.rect_tests++;
+            const float4 q0 = sc.rect[2 * (first + i)], q1 = sc.rect[2 * (first + i) + 1];
+            float t, ca, cb;
+            if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
+                tmax = t;
+                cur = dref(RR_TAG_RECT, first + i);
+            }
+        }
+    } else if (tag == RR_TAG_SPHERE) {
+        if (COUNT) cnt.sphere_tests++;
+        const float4 s = sc.sphere[idx];
+        float t;
+        if (test_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, tmax, t)) {
+            tmax = t;
+            cur = n;
+        }
+    } else if (tag == RR_TAG_TRIANGLE) {
+        if (COUNT) cnt.tri_tests++;
+        float t;
+        if (test_triangle(sc, idx, o, d, t)) {
+            tmax = t;
+            cur = n;
+        }
+    } else {  // RR_TAG_MOVING_SPHERE
+        if (COUNT) cnt.sphere_tests++;
+        const float4 a = sc.msphere[3 * idx], b = sc.msphere[3 * idx + 1], c = sc.msphere[3 * idx + 2];
+        float t;
+        if (test_sphere(msphere_center(a, b, time), c.x, o, d, tmin, tmax, t)) {
+            tmax = t;
+            cur = n;
+        }
+    }
+}
+
+__device__ __forceinline__ bool is_leaf_tag(uint32_t tag) { return tag <= RR_TAG_CUBOID; }  // sphere, moving sphere, rect, triangle, cuboid
+
+// Follow a chain of instances from the wave-uniform ref `n`, taking the ray along.
+__device__ __forceinline__ uint32_t peel_instances(const DevScene& sc, uint32_t n, f3& o, f3& d, uint32_t& peeled) {
+    peeled = 0;
+    while (dtag(n) == RR_TAG_INSTANCE) {
+        ++peeled;
+        const uint32_t idx = didx(n);
+        inst_apply_ray(sc, idx, o, d);
+        n = uni(__float_as_uint(sc.inst[2 * idx].y));
+    }
+    return n;
+}
+
+// SceneColliders::intersect (collider.rs:751-772) for the world ray (wo, wd): the root
+// list is folded child by child; (tmax, cur) carry the closest hit so far.
+template <bool COUNT>
+__device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, Rng& rng,
+                                         uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
+    uint32_t cur = NONE;
+    const uint32_t root_idx = uni(didx(sc.root));
+    const uint32_t first = uni(sc.list[root_idx].x), count = uni(sc.list[root_idx].y);
+    for (uint32_t i = 0; i < count; ++i) {
+        f3 o = wo, d = wd;
+        uint32_t n = uni(sc.child_refs[first + i]);
+        uint32_t peeled;
+        n = peel_instances(sc, n, o, d, peeled);
+        if (COUNT) cnt.inst_visits += peeled;
+        const uint32_t tag = dtag(n);
+        if (is_leaf_tag(tag)) {
+            eval_leaf<COUNT>(sc, n, o, d, time, tmin, tmax, cur, cnt);
+            continue;
+        }
+        if (tag == RR_TAG_MEDIUM) {
+            // collider.rs:435-475 with both boundary probes on the uniform path when the boundary
+            // is (instances of) a primitive or cuboid
+            const uint32_t midx = didx(n);
+            f3 bo = o, bd = d;
+            uint32_t chain;
+            const uint32_t b = peel_instances(sc, uni(sc.medium[midx].x), bo, bd, chain);
+            if (is_leaf_tag(dtag(b))) {
+                if (COUNT) cnt.inst_visits += 1 + chain;  // the medium, then the boundary's instances for probe 1
+                float t1 = kF32Max;
+                uint32_t c1 = NONE;
+                eval_leaf<COUNT>(sc, b, bo, bd, time, -kF32Max, t1, c1, cnt);
+                if (c1 != NONE) {
+                    if (COUNT) cnt.inst_visits += chain;  // probe 2 walks the boundary again
+                    float t2 = kF32Max;
+                    uint32_t c2 = NONE;
+                    eval_leaf<COUNT>(sc, b, bo, bd, time, t1 + 0.0001f, t2, c2, cnt);
+                    if (c2 != NONE) {
+                        if (t1 < tmin) t1 = tmin;
+                        if (t2 > tmax) t2 = tmax;
+                        if (t1 < t2) {
+                            if (t1 < 0.0f) t1 = 0.0f;
+                            const float ray_length = len3(d);
+                            const float dist_inside = (t2 - t1) * ray_length;
+                            const float hit_dist = __uint_as_float(sc.medium[midx].y) * log10f(rng.random());
+                            if (!(hit_dist > dist_inside)) {
+                                tmax = t1 + hit_dist / ray_length;
+                                cur = n;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+        }
+        machine<COUNT>(sc, n, wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
     }
     t_hit = tmax;
     ref_hit = cur;
@@ -792,10 +915,13 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
         out.terminal = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
         return false;
     }
-    if (m.type == RR_MAT_LAMBERTIAN) {  // material.rs:85-92: two draws for a direction nobody uses
-        rng_skip(g, 2);
+    // scatter (material.rs:85-169).  ray_color throws the scattered direction away (render.rs:32), so
+    // only the return value and the attenuation matter; random draws that can influence neither — the
+    // cosine direction of a Lambertian, a dielectric's reflect-or-refract coin, an isotropic direction —
+    // are not taken from the stream at all (the CPU oracle follows the same rule).
+    if (m.type == RR_MAT_LAMBERTIAN) {  // material.rs:85-92
         attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
-    } else if (m.type == RR_MAT_GLOSSY) {  // material.rs:121-126
+    } else if (m.type == RR_MAT_GLOSSY) {  // material.rs:121-126: the fuzz draw decides whether the path ends
         const f3 reflected = unit3(wd) - rec.n * 2.0f * dot3(unit3(wd), rec.n);
         const f3 sd = reflected + random_in_unit_sphere(g) * m.param;
         attenuation = mk3(m.r, m.g, m.b);
@@ -803,15 +929,9 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
             out.terminal = mk3(0.0f, 0.0f, 0.0f);
             return false;
         }
-    } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: one draw unless total internal reflection
+    } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: always scatters, attenuation 1
         attenuation = mk3(1.0f, 1.0f, 1.0f);
-        const float ratio = rec.front ? 1.0f / m.param : m.param;
-        const f3 ud = unit3(wd);
-        const float cos_theta = fminf(dot3(neg3(ud), rec.n), 1.0f);
-        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        if (!(ratio * sin_theta > 1.0f)) rng_skip(g, 1);
     } else {  // isotropic, material.rs:150-154
-        (void)random_in_unit_sphere(g);
         attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
     }
     // render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal
@@ -852,12 +972,14 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, uint32_t width, u
                                            f3& o, f3& d, float& time) {
     const float u = (float(i) + g.random()) / (float(width) - 1.0f);
     const float v = (float(j) + g.random()) / (float(height) - 1.0f);
-    float dx, dy;
-    for (;;) {  // vec3.rs:247-255
-        dx = g.randrange(-1.0f, 1.0f);
-        dy = g.randrange(-1.0f, 1.0f);
-        if (dx * dx + dy * dy + 0.0f * 0.0f >= 1.0f) continue;
-        break;
+    float dx = 0.0f, dy = 0.0f;
+    if (sc.cam.lens_radius != 0.0f) {  // with aperture 0 the lens sample is multiplied by zero: not drawn
+        for (;;) {                     // vec3.rs:247-255
+            dx = g.randrange(-1.0f, 1.0f);
+            dy = g.randrange(-1.0f, 1.0f);
+            if (dx * dx + dy * dy + 0.0f * 0.0f >= 1.0f) continue;
+            break;
+        }
     }
     const f3 rd = mk3(dx, dy, 0.0f) * sc.cam.lens_radius;
     const f3 offset = ld3(sc.cam.u) * rd.x + ld3(sc.cam.v) * rd.y;
