@@ -208,7 +208,8 @@ HOST_PROTOTYPES = {
     "rrh_flatten": (C.c_int, [vp, P(FlatScene)]),
 }
 
-HIP_LIB = os.path.join(PKG_DIR, "librr_hip.so")
+# RR_HIP_LIB points experiments (A/B builds of the kernels) at another build of the same ABI.
+HIP_LIB = os.environ.get("RR_HIP_LIB") or os.path.join(PKG_DIR, "librr_hip.so")
 HOST_LIB = os.path.join(PKG_DIR, "librr_host.so")
 
 

@@ -17,8 +17,8 @@ namespace rrdev {
 
 // ------------------------------------------------------------ packed refs
 // Device refs: index in bits 25..0, tag in bits 29..26, two spare bits 31..30.
-// In a BVH node the spare bits of `left` hold the split axis and bit 30 of `right`
-// holds has_box, so a node is exactly two 16-byte loads.
+// In a BVH node the spare bits of `left` hold the split axis and those of `right` two flags
+// (BVH_HAS_BOX, BVH_IMPURE), so a node is exactly two 16-byte loads.
 constexpr uint32_t IDX_BITS = 26;
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -31,10 +31,19 @@ __host__ __device__ inline uint32_t dextra(uint32_t r) { return r >> 30; }
 
 constexpr uint32_t MAX_CHAIN = 8;  // deepest instance nesting the device layout holds
 
-// Stack frame headers: kind in bits 31..28, record index below.
-constexpr uint32_t F_LIST = 1u << 28, F_BVH = 2u << 28, F_INST = 3u << 28, F_MED1 = 4u << 28, F_MED2 = 5u << 28;
-constexpr uint32_t F_KIND = 0xF0000000u;
-constexpr uint32_t FRAME_WORDS_LIST = 2, FRAME_WORDS_BVH = 2, FRAME_WORDS_INST = 1, FRAME_WORDS_MEDIUM = 5;
+constexpr uint32_t REF_MASK = (1u << 30) - 1u;
+constexpr uint32_t BVH_HAS_BOX = 1u << 30;  // in a node's `right`: the node has a bounding box
+constexpr uint32_t BVH_IMPURE = 1u << 31;   // in a node's `right`: a constant medium (which draws random numbers) lies below
+
+// Stack frames end in a word laid out like a ref.  A geometry tag in bits 29..26 makes it the
+// one-word frame of a BVH node whose first child is being evaluated: the low 30 bits are the
+// child to evaluate next.  Any other frame carries one of the codes below there and its record
+// index in bits 25..0.  Bit 30 keeps the caller's hit flag.
+constexpr uint32_t FK_LIST = 9, FK_INST = 10, FK_MED1 = 11, FK_MED2 = 12, FK_BVH2 = 13;
+constexpr uint32_t FW_FLAG = 1u << 30;
+constexpr uint32_t FW_MISS_NONE = 1u << 31;  // BVH frame: nothing is left to evaluate if the first child missed
+__host__ __device__ inline uint32_t frame_word(uint32_t kind, uint32_t idx) { return idx | (kind << IDX_BITS); }
+constexpr uint32_t FRAME_WORDS_LIST = 2, FRAME_WORDS_BVH = 1, FRAME_WORDS_INST = 1, FRAME_WORDS_MEDIUM = 5;
 
 struct DevMaterial {  // 32 B
     uint32_t type, texture;
@@ -51,31 +60,46 @@ struct DevImage {
     uint64_t offset;
 };
 
-struct DevScene {
-    const float4* bvh;          // 2 per node: (min.xyz, left), (max.xyz, right)
-    const float4* sphere;       // (center.xyz, radius)
-    const uint2* sphere_meta;   // (material, owner instance)
-    const float4* msphere;      // 3 per record: (c0.xyz, time0), (c1.xyz, time1), (radius, material, owner, -)
-    const float4* rect;         // 2 per record: (a0, a1, b0, b1), (k, axis, material, owner)
-    const float4* tri;          // 3 per record: p0.xyz p1.x | p1.yz p2.xy | p2.z n.xyz
-    const uint2* tri_meta;      // (material, owner instance)
-    const uint32_t* cuboid;     // first rect
-    const uint4* medium;        // (boundary, neg_inv_density bits, material, owner instance)
-    const float4* inst;         // 2 per record: (kind, child, v0, v1), (v2, depth, -, -)
-    const uint32_t* inst_chain; // MAX_CHAIN per instance: enclosing instances, outermost first, itself last
-    const uint2* list;          // (first child, n children)
-    const uint32_t* child_refs;
+// Loads through a constant-address-space pointer are always scalar loads when the address is
+// wave-uniform, and are issued where they are used instead of being kept in SGPRs for the
+// whole kernel.  On the host the qualifier vanishes; the layout is the same.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RR_CONST_AS __attribute__((address_space(4)))
+#else
+#define RR_CONST_AS
+#endif
+
+// What only shading and ray generation read (once per bounce or per sample): kept in device
+// memory behind one pointer so that its ~60 dwords do not occupy SGPRs during traversal.
+struct DevConst {
+    const uint2* sphere_meta;     // (material, owner instance)
+    const uint2* tri_meta;        // (material, owner instance)
     const DevMaterial* materials;
     const DevTexture* textures;
     const float* perlin_vec;      // 256*3 per table
     const uint8_t* perlin_perm;   // 3*256 per table
     const DevImage* images;
     const uint8_t* image_bytes;
-    uint32_t root;  // device ref of the top-level list
     uint32_t light_is_xzrect;
     float light_x0, light_x1, light_z0, light_z1, light_k;
     rr_camera cam;
     float background[3];
+};
+
+struct DevScene {  // kernel argument
+    const float4* bvh;          // 2 per node: (min.xyz, left), (max.xyz, right)
+    const float4* sphere;       // (center.xyz, radius)
+    const float4* msphere;      // 3 per record: (c0.xyz, time0), (c1.xyz, time1), (radius, material, owner, -)
+    const float4* rect;         // 2 per record: (a0, a1, b0, b1), (k, axis, material, owner)
+    const float4* tri;          // 3 per record: p0.xyz p1.x | p1.yz p2.xy | p2.z n.xyz
+    const float4* cuboid;       // 2 per record: (p0.xyz, first rect), (p1.xyz, 1 if the six rects are the constructor's)
+    const uint4* medium;        // (boundary, neg_inv_density bits, material, owner instance)
+    const float4* inst;         // 2 per record: (kind, child, v0, v1), (v2, depth, -, -)
+    const uint32_t* inst_chain; // MAX_CHAIN per instance: enclosing instances, outermost first, itself last
+    const uint2* list;          // (first child, n children)
+    const uint32_t* child_refs;
+    const RR_CONST_AS uint4* prog;  // scene program, 2 uint4 (one 32-byte op) per entry, terminated by OP_END
+    const RR_CONST_AS DevConst* k;
 };
 
 struct Counts {
@@ -259,15 +283,12 @@ __device__ __forceinline__ bool test_sphere(f3 center, float radius, f3 o, f3 d,
 
 __device__ __forceinline__ bool test_rect(float4 q0, float k, uint32_t axis, f3 o, f3 d, float tmin, float tmax, float& t,
                                           float& ca, float& cb) {
-    // collider.rs:344-353 / 367-376 / 405-414
-    float ok, dk, oa, da, ob, db;
-    if (axis == RR_RECT_XY) {
-        ok = o.z, dk = d.z, oa = o.x, da = d.x, ob = o.y, db = d.y;
-    } else if (axis == RR_RECT_XZ) {
-        ok = o.y, dk = d.y, oa = o.x, da = d.x, ob = o.z, db = d.z;
-    } else {
-        ok = o.x, dk = d.x, oa = o.y, da = d.y, ob = o.z, db = d.z;
-    }
+    // collider.rs:344-353 / 367-376 / 405-414; the plane is per-lane data here, so components are
+    // picked with selects rather than branches
+    const bool xy = axis == RR_RECT_XY, yz = axis == RR_RECT_YZ;
+    const float ok = xy ? o.z : (yz ? o.x : o.y), dk = xy ? d.z : (yz ? d.x : d.y);
+    const float oa = yz ? o.y : o.x, da = yz ? d.y : d.x;
+    const float ob = xy ? o.y : o.z, db = xy ? d.y : d.z;
     float tt = (k - ok) / dk;
     if (tt < tmin || tt > tmax) return false;
     float a = oa + tt * da;
@@ -279,9 +300,30 @@ __device__ __forceinline__ bool test_rect(float4 q0, float k, uint32_t axis, f3 
     return true;
 }
 
-__device__ __forceinline__ bool test_triangle(const DevScene& sc, uint32_t idx, f3 o, f3 d, float& t) {
+// Rect test with the plane fixed at compile time (collider.rs:344-353 / 367-376 / 405-414).
+template <uint32_t AXIS>
+__device__ __forceinline__ bool test_rect_axis(float a0, float a1, float b0, float b1, float k, f3 o, f3 d, float tmin, float tmax,
+                                               float& t) {
+    const float ok = AXIS == RR_RECT_XY ? o.z : (AXIS == RR_RECT_XZ ? o.y : o.x);
+    const float dk = AXIS == RR_RECT_XY ? d.z : (AXIS == RR_RECT_XZ ? d.y : d.x);
+    const float oa = AXIS == RR_RECT_YZ ? o.y : o.x, da = AXIS == RR_RECT_YZ ? d.y : d.x;
+    const float ob = AXIS == RR_RECT_XY ? o.y : o.z, db = AXIS == RR_RECT_XY ? d.y : d.z;
+    // One early exit after the division (measured 7 % faster on the Cornell box than none: most
+    // lanes of most waves fail the range test), then bitwise | so the rest is straight-line code.
+    // The reference's two `if (.. || ..) return None` let NaN through (every comparison is false),
+    // and so does this.
+    const float tt = (k - ok) / dk;
+    if (tt < tmin || tt > tmax) return false;
+    const float a = oa + tt * da;
+    const float b = ob + tt * db;
+    const bool out_of_range = (tt < tmin) | (tt > tmax);
+    const bool outside = (a < a0) | (a > a1) | (b < b0) | (b > b1);
+    t = tt;
+    return !(out_of_range | outside);
+}
+
+__device__ __forceinline__ bool test_triangle(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& t) {
     // collider.rs:627-661; the t range is not tested
-    const float4 q0 = sc.tri[3 * idx], q1 = sc.tri[3 * idx + 1], q2 = sc.tri[3 * idx + 2];
     const f3 p0 = mk3(q0.x, q0.y, q0.z), p1 = mk3(q0.w, q1.x, q1.y), p2 = mk3(q1.z, q1.w, q2.x), n = mk3(q2.y, q2.z, q2.w);
     float ndd = dot3(n, d);
     if (fabsf(ndd) < 0.000001f) return false;
@@ -328,6 +370,28 @@ __device__ __forceinline__ bool test_box(float4 lo, float4 hi, f3 o, f3 d, float
     return true;
 }
 
+// test_box with the three reciprocals of the direction already formed (same values, same tests).
+__device__ __forceinline__ bool test_box_inv(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float tmax) {
+    if (inv.x < 0.0f) {
+        const float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+        tmin = t1 > tmin ? t1 : tmin;
+        tmax = t0 < tmax ? t0 : tmax;
+    }
+    if (tmax <= tmin) return false;
+    if (inv.y < 0.0f) {
+        const float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
+        tmin = t1 > tmin ? t1 : tmin;
+        tmax = t0 < tmax ? t0 : tmax;
+    }
+    if (tmax <= tmin) return false;
+    if (inv.z < 0.0f) {
+        const float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
+        tmin = t1 > tmin ? t1 : tmin;
+        tmax = t0 < tmax ? t0 : tmax;
+    }
+    return !(tmax <= tmin);
+}
+
 __device__ __forceinline__ f3 msphere_center(float4 a, float4 b, float time) {  // collider.rs:269-271
     f3 c0 = mk3(a.x, a.y, a.z), c1 = mk3(b.x, b.y, b.z);
     return c0 + (c1 - c0) * ((time - a.w) / (b.w - a.w));
@@ -340,11 +404,11 @@ __device__ __forceinline__ f3 msphere_center(float4 a, float4 b, float time) {  
 // re-tests `left` (collider.rs:555-561), span-1 leaves are tested twice, triangles
 // accept any t >= 0 and every accepted hit replaces the previous one.
 //
-// State: (tmin, tmax, cur).  `cur` is the primitive (or medium) of the hit that the
-// innermost pending call would return, NONE if it would return None; tmax equals that
-// hit's t whenever cur is set.  Calls that start from "no hit yet" (the first child of
-// a BVH node, a medium's boundary probes) save the caller's `cur` in their frame and
-// restore it on a miss; every other recursive call is a tail call and needs no frame.
+// State: (tmin, tmax, cur, hitf).  `cur` is the primitive (or medium) of the last accepted
+// hit and tmax its t; a call that accepts nothing leaves both alone, so "the call returned
+// None" is "hitf is still clear".  Calls whose Some/None the caller branches on (the first
+// child of a BVH node, a medium's boundary probes) save the caller's hitf in their frame and
+// start with it clear; every other recursive call is a tail call and needs no frame.
 // Only (t, primitive) travel up the stack: point, normal, uv and the instance
 // post-transforms are recomputed once from them in reconstruct_hit().
 //
@@ -356,74 +420,123 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
     uint32_t cur = cur_io;
     uint32_t sp = 0;
     uint32_t node = start;
+    bool hitf = false;  // a hit was accepted since the innermost open first-child call or medium probe began
+    // aabb.rs:39 forms 1/direction anew in every box test; the quotient is the same every time, so
+    // it is formed once per ray space here
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     for (;;) {
         // ------------------------------------------------ evaluate `node`
         if (node != NONE) {
             const uint32_t tag = dtag(node), idx = didx(node);
+            // One address, three 16-byte loads and one wait for whatever kind of record each lane
+            // is at (every record array is padded by two words, so reading past a short record
+            // is harmless): lanes at BVH nodes and lanes at primitives wait together instead of
+            // one after the other.
+            const float4* rp = sc.bvh;
+            uint32_t roff = 2 * idx;
+            if (tag == RR_TAG_TRIANGLE) rp = sc.tri, roff = 3 * idx;
+            if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
+            if (tag == RR_TAG_RECT) rp = sc.rect;
+            if (tag == RR_TAG_CUBOID) rp = sc.cuboid;
+            if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere, roff = 3 * idx;
+            if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
+            const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
             if (tag == RR_TAG_BVH) {
-                const float4 lo = sc.bvh[2 * idx], hi = sc.bvh[2 * idx + 1];
-                const uint32_t left = __float_as_uint(lo.w), right = __float_as_uint(hi.w);
+                const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
                 bool pass = true;
-                if (dextra(right) & 1u) {
+                if (right & BVH_HAS_BOX) {
                     if (COUNT) cnt.box_tests++;
-                    pass = test_box(lo, hi, o, d, tmin, tmax);
+                    pass = test_box_inv(q0, q1, o, inv, tmin, tmax);
                 }
                 if (pass) {
+                    const uint32_t l = left & REF_MASK, r = right & REF_MASK;
                     const bool dirpos = comp(d, dextra(left)) >= 0.0f;
-                    stk[sp * stride] = cur;
-                    stk[(sp + 1) * stride] = F_BVH | idx;
-                    sp += 2;
-                    cur = NONE;
-                    node = (dirpos ? left : right) & ~(3u << 30);
+                    // Below a node without a constant medium every intersect call is a pure function
+                    // of (ray, t range): evaluating the same child twice over the same or a smaller
+                    // range cannot change the outcome.  The counting build evaluates everything.
+                    const bool pure = !COUNT && !(right & BVH_IMPURE);
+                    if (pure && l == r) {
+                        node = l;  // span-1 node: the second visit repeats the first
+                    } else {
+                        uint32_t fw;
+                        if (!dirpos)
+                            fw = l;  // right first; left follows after a hit and after a miss alike
+                        else if (pure)
+                            fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
+                        else
+                            fw = frame_word(FK_BVH2, idx);
+                        stk[sp * stride] = fw | (hitf ? FW_FLAG : 0u);
+                        sp += 1;
+                        hitf = false;
+                        node = dirpos ? l : r;
+                    }
                 } else {
                     node = NONE;
                 }
             } else if (tag == RR_TAG_SPHERE) {
                 if (COUNT) cnt.sphere_tests++;
-                const float4 s = sc.sphere[idx];
                 float t;
-                if (test_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, tmax, t)) {
+                if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, o, d, tmin, tmax, t)) {
                     tmax = t;
                     cur = node;
+                    hitf = true;
                 }
                 node = NONE;
             } else if (tag == RR_TAG_TRIANGLE) {
                 if (COUNT) cnt.tri_tests++;
                 float t;
-                if (test_triangle(sc, idx, o, d, t)) {
+                if (test_triangle(q0, q1, q2, o, d, t)) {
                     tmax = t;
                     cur = node;
+                    hitf = true;
                 }
                 node = NONE;
             } else if (tag == RR_TAG_RECT) {
                 if (COUNT) cnt.rect_tests++;
-                const float4 q0 = sc.rect[2 * idx], q1 = sc.rect[2 * idx + 1];
                 float t, ca, cb;
                 if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
                     tmax = t;
                     cur = node;
+                    hitf = true;
                 }
                 node = NONE;
             } else if (tag == RR_TAG_CUBOID) {
                 // six rects as a linear closest-hit list (collider.rs:428-430 → 751-772)
-                const uint32_t first = sc.cuboid[idx];
-                for (uint32_t i = 0; i < 6; ++i) {
-                    if (COUNT) cnt.rect_tests++;
-                    const float4 q0 = sc.rect[2 * (first + i)], q1 = sc.rect[2 * (first + i) + 1];
-                    float t, ca, cb;
-                    if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
-                        tmax = t;
-                        cur = dref(RR_TAG_RECT, first + i);
+                const uint32_t first = __float_as_uint(q0.w);
+                if (COUNT) cnt.rect_tests += 6;
+                if (__float_as_uint(q1.w) != 0u) {
+                    // the sides are the constructor's (collider.rs:419-426): all six follow from the corners
+                    float t;
+                    uint32_t side = NONE;
+                    if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q1.z, o, d, tmin, tmax, t)) tmax = t, side = 0;
+                    if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q0.z, o, d, tmin, tmax, t)) tmax = t, side = 1;
+                    if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q1.y, o, d, tmin, tmax, t)) tmax = t, side = 2;
+                    if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q0.y, o, d, tmin, tmax, t)) tmax = t, side = 3;
+                    if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q1.x, o, d, tmin, tmax, t)) tmax = t, side = 4;
+                    if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q0.x, o, d, tmin, tmax, t)) tmax = t, side = 5;
+                    if (side != NONE) {
+                        cur = dref(RR_TAG_RECT, first + side);
+                        hitf = true;
+                    }
+                } else {
+                    for (uint32_t i = 0; i < 6; ++i) {
+                        const float4 r0 = sc.rect[2 * (first + i)], r1 = sc.rect[2 * (first + i) + 1];
+                        float t, ca, cb;
+                        if (test_rect(r0, r1.x, __float_as_uint(r1.y), o, d, tmin, tmax, t, ca, cb)) {
+                            tmax = t;
+                            cur = dref(RR_TAG_RECT, first + i);
+                            hitf = true;
+                        }
                     }
                 }
                 node = NONE;
             } else if (tag == RR_TAG_MOVING_SPHERE) {
                 if (COUNT) cnt.sphere_tests++;
-                const float4 a = sc.msphere[3 * idx], b = sc.msphere[3 * idx + 1], c = sc.msphere[3 * idx + 2];
                 float t;
-                if (test_sphere(msphere_center(a, b, time), c.x, o, d, tmin, tmax, t)) {
+                if (test_sphere(msphere_center(q0, q1, time), q2.x, o, d, tmin, tmax, t)) {
                     tmax = t;
                     cur = node;
+                    hitf = true;
                 }
                 node = NONE;
             } else if (tag == RR_TAG_LIST) {
@@ -432,15 +545,16 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
                     node = NONE;
                 } else {
                     stk[sp * stride] = l.x + 1;
-                    stk[(sp + 1) * stride] = F_LIST | idx;
+                    stk[(sp + 1) * stride] = frame_word(FK_LIST, idx);
                     sp += 2;
                     node = sc.child_refs[l.x];
                 }
             } else if (tag == RR_TAG_INSTANCE) {
                 if (COUNT) cnt.inst_visits++;
-                stk[sp * stride] = F_INST | idx;
+                stk[sp * stride] = frame_word(FK_INST, idx);
                 sp += 1;
                 inst_apply_ray(sc, idx, o, d);
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 node = __float_as_uint(sc.inst[2 * idx].y);
             } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
                 if (COUNT) cnt.inst_visits++;
@@ -448,32 +562,36 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
                 stk[(sp + 1) * stride] = __float_as_uint(tmax);
                 stk[(sp + 2) * stride] = cur;
                 stk[(sp + 3) * stride] = 0u;
-                stk[(sp + 4) * stride] = F_MED1 | idx;
+                stk[(sp + 4) * stride] = frame_word(FK_MED1, idx) | (hitf ? FW_FLAG : 0u);
                 sp += 5;
                 tmin = -kF32Max;
                 tmax = kF32Max;
-                cur = NONE;
+                hitf = false;
                 node = sc.medium[idx].x;
             }
         }
-        // ------------------------------------------- return to the caller
-        if (node == NONE) {
-            if (sp == 0) break;
-            const uint32_t hdr = stk[(sp - 1) * stride];
-            const uint32_t kind = hdr & F_KIND, idx = hdr & ~F_KIND;
-            if (kind == F_BVH) {
-                // collider.rs:546-580 after the first child came back
-                const uint32_t saved = stk[(sp - 2) * stride];
-                sp -= 2;
-                const uint32_t left = __float_as_uint(sc.bvh[2 * idx].w), right = __float_as_uint(sc.bvh[2 * idx + 1].w);
-                const bool dirpos = comp(d, dextra(left)) >= 0.0f;
-                if (cur != NONE) {
-                    node = (dirpos ? right : left) & ~(3u << 30);  // second child, t_max = first hit's t
-                } else {
-                    cur = saved;
-                    node = left & ~(3u << 30);  // both branches re-enter `left` after a miss
-                }
-            } else if (kind == F_LIST) {
+        // ------------------------------------------- return to the callers
+        bool done = false;
+        while (node == NONE) {
+            if (sp == 0) {
+                done = true;
+                break;
+            }
+            const uint32_t fw = stk[(sp - 1) * stride];
+            const uint32_t kind = dtag(fw), idx = didx(fw);
+            if (kind <= RR_TAG_LIST) {
+                // collider.rs:546-580 after the first child came back: the frame names what comes next
+                sp -= 1;
+                const bool first_hit = hitf;
+                hitf = first_hit || (fw & FW_FLAG);
+                node = (!first_hit && (fw & FW_MISS_NONE)) ? NONE : (fw & REF_MASK);
+            } else if (kind == FK_BVH2) {
+                // left went first: right with t_max = the hit's t, or left once more after a miss
+                sp -= 1;
+                const bool first_hit = hitf;
+                hitf = first_hit || (fw & FW_FLAG);
+                node = __float_as_uint(first_hit ? sc.bvh[2 * idx + 1].w : sc.bvh[2 * idx].w) & REF_MASK;
+            } else if (kind == FK_LIST) {
                 const uint32_t pos = stk[(sp - 2) * stride];
                 const uint2 l = sc.list[idx];
                 if (pos < l.x + l.y) {
@@ -482,32 +600,35 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
                 } else {
                     sp -= 2;
                 }
-            } else if (kind == F_INST) {
+            } else if (kind == FK_INST) {
                 sp -= 1;
                 const uint32_t depth = inst_depth(sc, idx);
                 localize(sc, idx, depth - 1, wo, wd, o, d);  // back to the enclosing space, recomputed from the world ray
-            } else if (kind == F_MED1) {
-                if (cur == NONE) {
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            } else if (kind == FK_MED1) {
+                if (!hitf) {
                     tmin = __uint_as_float(stk[(sp - 5) * stride]);
                     tmax = __uint_as_float(stk[(sp - 4) * stride]);
                     cur = stk[(sp - 3) * stride];
+                    hitf = (fw & FW_FLAG) != 0u;
                     sp -= 5;
                 } else {  // second probe over (t1 + 0.0001, f32::MAX), collider.rs:443
                     const float t1 = tmax;
                     stk[(sp - 2) * stride] = __float_as_uint(t1);
-                    stk[(sp - 1) * stride] = F_MED2 | idx;
+                    stk[(sp - 1) * stride] = frame_word(FK_MED2, idx) | (fw & FW_FLAG);
                     tmin = t1 + 0.0001f;
                     tmax = kF32Max;
-                    cur = NONE;
+                    hitf = false;
                     node = sc.medium[idx].x;
                 }
-            } else {  // F_MED2
-                const bool found = cur != NONE;
+            } else {  // FK_MED2
+                const bool found = hitf;
                 float t2 = tmax;
                 float t1 = __uint_as_float(stk[(sp - 2) * stride]);
                 tmin = __uint_as_float(stk[(sp - 5) * stride]);
                 tmax = __uint_as_float(stk[(sp - 4) * stride]);
                 cur = stk[(sp - 3) * stride];
+                hitf = (fw & FW_FLAG) != 0u;
                 sp -= 5;
                 if (found) {  // collider.rs:448-474
                     if (t1 < tmin) t1 = tmin;
@@ -520,11 +641,13 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
                         if (!(hit_dist > dist_inside)) {
                             tmax = t1 + hit_dist / ray_length;
                             cur = dref(RR_TAG_MEDIUM, idx);
+                            hitf = true;
                         }
                     }
                 }
             }
         }
+        if (done) break;
     }
     tmax_io = tmax;
     cur_io = cur;
@@ -552,7 +675,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
             cur = n;
         }
     } else if (tag == RR_TAG_CUBOID) {  // collider.rs:428-430 → 751-772
-        const uint32_t first = uni(sc.cuboid[idx]);
+        const uint32_t first = uni(__float_as_uint(sc.cuboid[2 * idx].w));
 #pragma unroll
         for (uint32_t i = 0; i < 6; ++i) {
             if (COUNT) cnt.rect_tests++;
@@ -574,7 +697,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
     } else if (tag == RR_TAG_TRIANGLE) {
         if (COUNT) cnt.tri_tests++;
         float t;
-        if (test_triangle(sc, idx, o, d, t)) {
+        if (test_triangle(sc.tri[3 * idx], sc.tri[3 * idx + 1], sc.tri[3 * idx + 2], o, d, t)) {
             tmax = t;
             cur = n;
         }
@@ -589,75 +712,119 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
     }
 }
 
-__device__ __forceinline__ bool is_leaf_tag(uint32_t tag) { return tag <= RR_TAG_CUBOID; }  // sphere, moving sphere, rect, triangle, cuboid
+// The scene program: the part of the tree that every ray walks in the same order (root list,
+// nested lists, instances, cuboids, media, top-level primitives), compiled at upload time
+// into a linear array of 32-byte ops.  One wave executes it with scalar control flow and one
+// scalar load per op; BVH subtrees and anything else that is data dependent are single ops
+// that hand a subtree to the per-lane machine.  Op words: w0 = code | flags << 8, w1 = ref,
+// w2..w7 = six f32 operands.
+constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
+                   OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
+                   OP_MED_MID = 13, OP_MED_END = 14;
+constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
 
-// Follow a chain of instances from the wave-uniform ref `n`, taking the ray along.
-__device__ __forceinline__ uint32_t peel_instances(const DevScene& sc, uint32_t n, f3& o, f3& d, uint32_t& peeled) {
-    peeled = 0;
-    while (dtag(n) == RR_TAG_INSTANCE) {
-        ++peeled;
-        const uint32_t idx = didx(n);
-        inst_apply_ray(sc, idx, o, d);
-        n = uni(__float_as_uint(sc.inst[2 * idx].y));
-    }
-    return n;
-}
+struct Op {
+    uint32_t code, ref;
+    float f0, f1, f2, f3, f4, f5;
+};
 
-// SceneColliders::intersect (collider.rs:751-772) for the world ray (wo, wd): the root
-// list is folded child by child; (tmax, cur) carry the closest hit so far.
+// SceneColliders::intersect (collider.rs:751-772) for the world ray (wo, wd).  (tmax, cur) carry
+// the closest hit so far through the fold; `live` is false only for lanes whose first medium
+// probe missed, until that medium's end op.
 template <bool COUNT>
-__device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, Rng& rng,
-                                         uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
+__device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, bool enabled,
+                                         Rng& rng, uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
+    // `enabled` is false for lanes that only ride along (the caller keeps this call in wave-uniform
+    // control flow): they execute the program but record no hit and count nothing.
     uint32_t cur = NONE;
-    const uint32_t root_idx = uni(didx(sc.root));
-    const uint32_t first = uni(sc.list[root_idx].x), count = uni(sc.list[root_idx].y);
-    for (uint32_t i = 0; i < count; ++i) {
-        f3 o = wo, d = wd;
-        uint32_t n = uni(sc.child_refs[first + i]);
-        uint32_t peeled;
-        n = peel_instances(sc, n, o, d, peeled);
-        if (COUNT) cnt.inst_visits += peeled;
-        const uint32_t tag = dtag(n);
-        if (is_leaf_tag(tag)) {
-            eval_leaf<COUNT>(sc, n, o, d, time, tmin, tmax, cur, cnt);
-            continue;
-        }
-        if (tag == RR_TAG_MEDIUM) {
-            // collider.rs:435-475 with both boundary probes on the uniform path when the boundary
-            // is (instances of) a primitive or cuboid
-            const uint32_t midx = didx(n);
-            f3 bo = o, bd = d;
-            uint32_t chain;
-            const uint32_t b = peel_instances(sc, uni(sc.medium[midx].x), bo, bd, chain);
-            if (is_leaf_tag(dtag(b))) {
-                if (COUNT) cnt.inst_visits += 1 + chain;  // the medium, then the boundary's instances for probe 1
-                float t1 = kF32Max;
-                uint32_t c1 = NONE;
-                eval_leaf<COUNT>(sc, b, bo, bd, time, -kF32Max, t1, c1, cnt);
-                if (c1 != NONE) {
-                    if (COUNT) cnt.inst_visits += chain;  // probe 2 walks the boundary again
-                    float t2 = kF32Max;
-                    uint32_t c2 = NONE;
-                    eval_leaf<COUNT>(sc, b, bo, bd, time, t1 + 0.0001f, t2, c2, cnt);
-                    if (c2 != NONE) {
-                        if (t1 < tmin) t1 = tmin;
-                        if (t2 > tmax) t2 = tmax;
-                        if (t1 < t2) {
-                            if (t1 < 0.0f) t1 = 0.0f;
-                            const float ray_length = len3(d);
-                            const float dist_inside = (t2 - t1) * ray_length;
-                            const float hit_dist = __uint_as_float(sc.medium[midx].y) * log10f(rng.random());
-                            if (!(hit_dist > dist_inside)) {
-                                tmax = t1 + hit_dist / ray_length;
-                                cur = n;
-                            }
-                        }
+    f3 o = wo, d = wd;
+    bool live = enabled;
+    float m_tmin = 0.0f, m_tmax = 0.0f, m_t1 = 0.0f;  // the enclosing call's range and probe 1 of the open medium
+    uint32_t m_cur = NONE;
+    const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
+    Op next = prog[0];
+    uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
+    for (;;) {
+        // the op after this one is fetched while this one executes (the program ends in two OP_ENDs)
+        const Op op = next;
+        pc = uni(pc + 1);
+        next = prog[pc];
+        const uint32_t code = uni(op.code) & 0xFFu;
+        if (code == OP_END) break;
+        if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
+            if (COUNT && live) cnt.rect_tests++;
+            float t;
+            bool hit;
+            if (code == OP_RECT_XY)
+                hit = test_rect_axis<RR_RECT_XY>(op.f0, op.f1, op.f2, op.f3, op.f4, o, d, tmin, tmax, t);
+            else if (code == OP_RECT_XZ)
+                hit = test_rect_axis<RR_RECT_XZ>(op.f0, op.f1, op.f2, op.f3, op.f4, o, d, tmin, tmax, t);
+            else
+                hit = test_rect_axis<RR_RECT_YZ>(op.f0, op.f1, op.f2, op.f3, op.f4, o, d, tmin, tmax, t);
+            hit &= live;
+            tmax = hit ? t : tmax;
+            cur = hit ? op.ref : cur;
+        } else if (code == OP_RESET) {
+            o = wo;
+            d = wd;
+        } else if (code == OP_TRANSLATE) {  // collider.rs:481
+            if (COUNT && live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+            o = o - mk3(op.f0, op.f1, op.f2);
+        } else if (code >= OP_ROT_X && code <= OP_ROT_Z) {  // collider.rs:499-509
+            if (COUNT && live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+            const float s = op.f0, c = op.f1;
+            f3 no = o, nd = d;
+            if (code == OP_ROT_Y) {
+                no.x = c * o.x - s * o.z, no.z = s * o.x + c * o.z;
+                nd.x = c * d.x - s * d.z, nd.z = s * d.x + c * d.z;
+            } else if (code == OP_ROT_X) {
+                no.y = c * o.y - s * o.z, no.z = s * o.y + c * o.z;
+                nd.y = c * d.y - s * d.z, nd.z = s * d.y + c * d.z;
+            } else {
+                no.x = c * o.x - s * o.y, no.y = s * o.x + c * o.y;
+                nd.x = c * d.x - s * d.y, nd.y = s * d.x + c * d.y;
+            }
+            o = no;
+            d = nd;
+        } else if (code == OP_SPHERE) {
+            if (COUNT && live) cnt.sphere_tests++;
+            float t;
+            if (test_sphere(mk3(op.f0, op.f1, op.f2), op.f3, o, d, tmin, tmax, t) && live) {
+                tmax = t;
+                cur = op.ref;
+            }
+        } else if (code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
+            if (live) eval_leaf<COUNT>(sc, uni(op.ref), o, d, time, tmin, tmax, cur, cnt);
+        } else if (code == OP_SUBTREE) {  // BVH (or any shape the program does not flatten): per-lane machine
+            if (live) machine<COUNT>(sc, uni(op.ref), wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
+        } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
+            if (COUNT && live) cnt.inst_visits++;
+            m_tmin = tmin, m_tmax = tmax, m_cur = cur;
+            tmin = -kF32Max, tmax = kF32Max, cur = NONE;
+        } else if (code == OP_MED_MID) {  // collider.rs:443: second probe over (t1 + 0.0001, f32::MAX)
+            live = cur != NONE;
+            m_t1 = tmax;
+            tmin = m_t1 + 0.0001f, tmax = kF32Max, cur = NONE;
+        } else {  // OP_MED_END, collider.rs:448-474
+            const bool found = live && cur != NONE;
+            float t1 = m_t1, t2 = tmax;
+            tmin = m_tmin, tmax = m_tmax, cur = m_cur;
+            live = enabled;
+            if (found) {
+                if (t1 < tmin) t1 = tmin;
+                if (t2 > tmax) t2 = tmax;
+                if (t1 < t2) {
+                    if (t1 < 0.0f) t1 = 0.0f;
+                    const float ray_length = len3(d);
+                    const float dist_inside = (t2 - t1) * ray_length;
+                    const float hit_dist = op.f0 * log10f(rng.random());
+                    if (!(hit_dist > dist_inside)) {
+                        tmax = t1 + hit_dist / ray_length;
+                        cur = op.ref;
                     }
                 }
-                continue;
             }
         }
-        machine<COUNT>(sc, n, wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
     }
     t_hit = tmax;
     ref_hit = cur;
@@ -684,7 +851,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     uint32_t owner;
     float4 r0, r1;  // record words reused below
     if (tag == RR_TAG_SPHERE) {
-        const uint2 m = sc.sphere_meta[idx];
+        const uint2 m = sc.k->sphere_meta[idx];
         h.mat = m.x;
         owner = m.y;
         r0 = sc.sphere[idx];
@@ -694,7 +861,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
         h.mat = __float_as_uint(r1.z);
         owner = __float_as_uint(r1.w);
     } else if (tag == RR_TAG_TRIANGLE) {
-        const uint2 m = sc.tri_meta[idx];
+        const uint2 m = sc.k->tri_meta[idx];
         h.mat = m.x;
         owner = m.y;
         r0 = sc.tri[3 * idx + 2];
@@ -783,8 +950,8 @@ __device__ inline float perlin_noise(const DevScene& sc, uint32_t table, f3 p) {
     const float uu = u * u * (3.0f - 2.0f * u);
     const float vv = v * v * (3.0f - 2.0f * v);
     const float ww = w * w * (3.0f - 2.0f * w);
-    const uint8_t* px = sc.perlin_perm + table * 768u;
-    const float* vec = sc.perlin_vec + table * 768u;
+    const uint8_t* px = sc.k->perlin_perm + table * 768u;
+    const float* vec = sc.k->perlin_vec + table * 768u;
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; ++di)
@@ -824,7 +991,7 @@ __device__ __forceinline__ uint32_t f32_as_u32_sat(float f) {  // Rust `as u32`
 }
 
 __device__ inline f3 texture_color(const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
-    const DevTexture& t = sc.textures[tex];
+    const DevTexture& t = sc.k->textures[tex];
     const uint32_t type = t.type;
     if (type == RR_TEX_SOLID) return mk3(t.c0[0], t.c0[1], t.c0[2]);
     if (type == RR_TEX_CHECKERED) {
@@ -835,14 +1002,14 @@ __device__ inline f3 texture_color(const DevScene& sc, uint32_t tex, float u, fl
         const float tv = perlin_turb(sc, t.index, p, t.depth);
         return mk3(1.0f, 1.0f, 1.0f) * 0.5f * (1.0f + sinf(t.scale * p.z + 10.0f * tv));
     }
-    const DevImage im = sc.images[t.index];
+    const DevImage im = sc.k->images[t.index];
     const float uc = clampf(u, 0.0f, 1.0f);
     const float vc = 1.0f - clampf(v, 0.0f, 1.0f);
     uint32_t i = f32_as_u32_sat(uc * float(im.width));
     uint32_t j = f32_as_u32_sat(vc * float(im.height));
     if (i >= im.width) i = im.width - 1;
     if (j >= im.height) j = im.height - 1;
-    const uint8_t* px = sc.image_bytes + im.offset + (static_cast<uint64_t>(j) * im.width + i) * 3u;
+    const uint8_t* px = sc.k->image_bytes + im.offset + (static_cast<uint64_t>(j) * im.width + i) * 3u;
     const float cs = 1.0f / 255.0f;
     return mk3(float(px[0]) * cs, float(px[1]) * cs, float(px[2]) * cs);
 }
@@ -875,14 +1042,14 @@ __device__ __forceinline__ float reflectance(float cosin, float ref_idx) {  // m
 }
 
 __device__ __forceinline__ float light_pdf_value(const DevScene& sc, f3 origin, f3 v) {  // collider.rs:389-399, 714-719
-    if (!sc.light_is_xzrect) return 0.0f;
+    if (!sc.k->light_is_xzrect) return 0.0f;
     float t, ca, cb;
-    if (!test_rect(make_float4(sc.light_x0, sc.light_x1, sc.light_z0, sc.light_z1), sc.light_k, RR_RECT_XZ, origin, v, 0.001f,
+    if (!test_rect(make_float4(sc.k->light_x0, sc.k->light_x1, sc.k->light_z0, sc.k->light_z1), sc.k->light_k, RR_RECT_XZ, origin, v, 0.001f,
                    kF32Max, t, ca, cb))
         return 0.0f;
     const f3 outn = mk3(0.0f, 1.0f, 0.0f);
     const f3 n = dot3(v, outn) < 0.0f ? outn : neg3(outn);
-    const float area = (sc.light_x1 - sc.light_x0) * (sc.light_z1 - sc.light_z0);
+    const float area = (sc.k->light_x1 - sc.k->light_x0) * (sc.k->light_z1 - sc.k->light_z0);
     const float dist_sqrd = t * t * len2(v);
     const float cosine = fabsf(dot3(v, n) / len3(v));
     return dist_sqrd / (cosine * area);
@@ -899,7 +1066,7 @@ struct Bounce {
 };
 __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, Rng& g, Bounce& out) {
     if (ref == NONE) {
-        out.terminal = ld3(sc.background);
+        out.terminal = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
         return false;
     }
     // which records need u,v: only image textures read them
@@ -907,9 +1074,9 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     {
         // material id is needed before reconstruct can know about uv, so reconstruct asks for
         // uv whenever the scene has images at all
-        rec = reconstruct_hit(sc, wo, wd, time, t, ref, sc.images != nullptr);
+        rec = reconstruct_hit(sc, wo, wd, time, t, ref, sc.k->images != nullptr);
     }
-    const DevMaterial m = sc.materials[rec.mat];
+    const DevMaterial m = sc.k->materials[rec.mat];
     f3 attenuation;
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
         out.terminal = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
@@ -941,10 +1108,10 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     const f3 u = cross3(w, v);
     f3 dir;
     if (g.random() < 0.5f) {  // pdf.rs:51-53 → collider.rs:400-403 / 720-725
-        if (sc.light_is_xzrect) {
-            const float x = g.randrange(sc.light_x0, sc.light_x1);
-            const float z = g.randrange(sc.light_z0, sc.light_z1);
-            dir = mk3(x, sc.light_k, z) - rec.p;
+        if (sc.k->light_is_xzrect) {
+            const float x = g.randrange(sc.k->light_x0, sc.k->light_x1);
+            const float z = g.randrange(sc.k->light_z0, sc.k->light_z1);
+            dir = mk3(x, sc.k->light_k, z) - rec.p;
         } else {
             dir = mk3(1.0f, 0.0f, 0.0f);
         }
@@ -973,7 +1140,7 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, uint32_t width, u
     const float u = (float(i) + g.random()) / (float(width) - 1.0f);
     const float v = (float(j) + g.random()) / (float(height) - 1.0f);
     float dx = 0.0f, dy = 0.0f;
-    if (sc.cam.lens_radius != 0.0f) {  // with aperture 0 the lens sample is multiplied by zero: not drawn
+    if (sc.k->cam.lens_radius != 0.0f) {  // with aperture 0 the lens sample is multiplied by zero: not drawn
         for (;;) {                     // vec3.rs:247-255
             dx = g.randrange(-1.0f, 1.0f);
             dy = g.randrange(-1.0f, 1.0f);
@@ -981,12 +1148,12 @@ __device__ __forceinline__ void camera_ray(const DevScene& sc, uint32_t width, u
             break;
         }
     }
-    const f3 rd = mk3(dx, dy, 0.0f) * sc.cam.lens_radius;
-    const f3 offset = ld3(sc.cam.u) * rd.x + ld3(sc.cam.v) * rd.y;
-    const f3 origin = ld3(sc.cam.origin);
+    const f3 rd = mk3(dx, dy, 0.0f) * sc.k->cam.lens_radius;
+    const f3 offset = mk3(sc.k->cam.u[0], sc.k->cam.u[1], sc.k->cam.u[2]) * rd.x + mk3(sc.k->cam.v[0], sc.k->cam.v[1], sc.k->cam.v[2]) * rd.y;
+    const f3 origin = mk3(sc.k->cam.origin[0], sc.k->cam.origin[1], sc.k->cam.origin[2]);
     o = origin + offset;
-    d = ld3(sc.cam.lower_left) + ld3(sc.cam.horizontal) * u + ld3(sc.cam.vertical) * v - origin - offset;
-    time = g.randrange(sc.cam.shutter_open, sc.cam.shutter_close);
+    d = mk3(sc.k->cam.lower_left[0], sc.k->cam.lower_left[1], sc.k->cam.lower_left[2]) + mk3(sc.k->cam.horizontal[0], sc.k->cam.horizontal[1], sc.k->cam.horizontal[2]) * u + mk3(sc.k->cam.vertical[0], sc.k->cam.vertical[1], sc.k->cam.vertical[2]) * v - origin - offset;
+    time = g.randrange(sc.k->cam.shutter_open, sc.k->cam.shutter_close);
 }
 
 }  // namespace rrdev

@@ -19,6 +19,10 @@
 using namespace rrdev;
 
 // ================================================================= kernels
+// Minimum waves per SIMD the register allocator must leave room for in the render kernel.
+#ifndef RR_RENDER_WAVES_PER_SIMD
+#define RR_RENDER_WAVES_PER_SIMD 4
+#endif
 struct RenderArgs {
     uint32_t width, height;
     uint32_t spt;           // samples per slice and pixel (render.rs:130)
@@ -53,7 +57,7 @@ __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
+__global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
                                                 unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
@@ -69,59 +73,82 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, RenderArgs a, float
     float time = 0.f;
     uint32_t depth_left = 0, bounce = 0, sample = 0, pixel_key = 0;
 
+    // The loop below is uniform per wave (its only exit is a wave vote); lanes differ through
+    // flags.  That keeps the scene-program interpreter inside traverse() in uniform control
+    // flow, where its program counter, op words and branches stay on the scalar unit.
+    bool lane_done = false;
     for (;;) {
-        if (!path_active) {
-            if (!have_item) {
-                bool found = false;
-                while (q < a.n_items) {
-                    const uint32_t r = static_cast<uint32_t>(q % a.padded_pixels);
-                    sl = static_cast<uint32_t>(q / a.padded_pixels);
-                    const uint32_t tile = r >> 6, within = r & 63u;
-                    px = (tile % a.tiles_x) * 8u + (within & 7u);
-                    py = (tile / a.tiles_x) * 8u + (within >> 3);
-                    if (px < a.width && py < a.height) {
-                        found = true;
+        // ---- refill: lanes whose path ended take their next sample, or their next work item
+        if (!path_active && !lane_done) {
+            for (;;) {
+                if (!have_item) {
+                    bool found = false;
+                    while (q < a.n_items) {
+                        const uint32_t r = static_cast<uint32_t>(q % a.padded_pixels);
+                        sl = static_cast<uint32_t>(q / a.padded_pixels);
+                        const uint32_t tile = r >> 6, within = r & 63u;
+                        px = (tile % a.tiles_x) * 8u + (within & 7u);
+                        py = (tile / a.tiles_x) * 8u + (within >> 3);
+                        if (px < a.width && py < a.height) {
+                            found = true;
+                            break;
+                        }
+                        q += item_stride;
+                    }
+                    if (!found) {
+                        lane_done = true;
                         break;
                     }
-                    q += item_stride;
+                    have_item = true;
+                    s = 0;
+                    acc = mk3(0.f, 0.f, 0.f);
+                    pixel_key = py * a.width + px;
                 }
-                if (!found) break;
-                have_item = true;
-                s = 0;
-                acc = mk3(0.f, 0.f, 0.f);
-                pixel_key = py * a.width + px;
-            }
-            if (s == a.spt) {  // pixel_color of render.rs:93-100 is complete for this slice
+                if (s != a.spt) break;
+                // pixel_color of render.rs:93-100 is complete for this slice
                 float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.height + py) * a.width + px) * 3u;
                 dst[0] = acc.x;
                 dst[1] = acc.y;
                 dst[2] = acc.z;
                 have_item = false;
                 q += item_stride;
-                continue;
             }
-            sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
-            Rng g;
-            g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
-            camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
-            thr = mk3(1.f, 1.f, 1.f);
-            depth_left = a.max_depth;
-            bounce = 0;
-            path_active = true;
-            cnt.samples++;
+            if (!lane_done) {
+                sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
+                Rng g;
+                g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
+                camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
+                thr = mk3(1.f, 1.f, 1.f);
+                depth_left = a.max_depth;
+                bounce = 0;
+                path_active = true;
+                cnt.samples++;
+            }
         }
-        // one ray_color call (render.rs:15-41)
+        if (!__any(path_active)) break;
+        // ---- one ray_color call (render.rs:15-41) for every lane that has a path
+        const bool run = path_active && depth_left != 0;
+        if (run) cnt.rays++;
+        Rng g;
+        g.start(a.seed, pixel_key, sample, bounce);
+        float t;
+        uint32_t ref;
+#ifdef RR_ABLATE_TRAVERSE  // timing-only build: wrong images, used to price the sections of a bounce
+        t = ro.x + rd.y;
+        ref = NONE;
+#else
+        traverse<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+#endif
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
-        if (depth_left != 0) {
-            cnt.rays++;
-            Rng g;
-            g.start(a.seed, pixel_key, sample, bounce);
-            float t;
-            uint32_t ref;
-            traverse<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, g, stk, stride, t, ref, cnt);
+        if (run) {
             Bounce b;
+#ifdef RR_ABLATE_SHADE
+            go_on = false;
+            b.terminal = mk3(t, __uint_as_float(ref), g.random());
+#else
             go_on = shade(sc, ro, rd, time, t, ref, g, b);
+#endif
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
@@ -132,7 +159,7 @@ __global__ void __launch_bounds__(256) k_render(DevScene sc, RenderArgs a, float
                 terminal = b.terminal;
             }
         }
-        if (!go_on) {
+        if (path_active && !go_on) {
             acc = acc + thr * terminal;  // render.rs:99
             s += 1;
             path_active = false;
@@ -156,7 +183,7 @@ __global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, c
     Counts cnt = {0, 0, 0, 0, 0, 0, 0};
     float t;
     uint32_t ref;
-    traverse<false>(sc, o, d, time, t_min, t_max, g, stk, blockDim.x, t, ref, cnt);
+    traverse<false>(sc, o, d, time, t_min, t_max, true, g, stk, blockDim.x, t, ref, cnt);
     float* of = out_f + static_cast<uint64_t>(i) * 12u;
     out_ref[i] = ref;
     if (ref == NONE) {
@@ -250,6 +277,8 @@ struct Walker {
     std::vector<uint8_t> seen[RR_TAG_COUNT];
     std::vector<uint32_t> owner_sphere, owner_msphere, owner_rect, owner_tri, owner_medium;
     std::vector<uint32_t> inst_depth, inst_chain;
+    std::vector<uint8_t> bvh_impure;  // a constant medium lies below this node
+    uint32_t media_walked = 0;
     uint32_t max_inst_depth = 0;
     std::string err;
     int err_code = RR_E_INVALID;
@@ -265,6 +294,7 @@ struct Walker {
         owner_medium.assign(s.n_media, NONE);
         inst_depth.assign(s.n_instances, 0);
         inst_chain.assign(static_cast<size_t>(s.n_instances) * MAX_CHAIN, NONE);
+        bvh_impure.assign(s.n_bvh_nodes, 0);
     }
 
     bool bad(const std::string& m, int code = RR_E_INVALID) {
@@ -311,6 +341,7 @@ struct Walker {
             }
             case RR_TAG_MEDIUM: {
                 owner_medium[idx] = owner;
+                ++media_walked;
                 if (!mat_ok(s.media[idx].material)) return false;
                 uint32_t w;
                 if (!walk(s.media[idx].boundary, owner, level + 1, w)) return false;
@@ -335,12 +366,14 @@ struct Walker {
                 const rr_bvh_node& n = s.bvh_nodes[idx];
                 if (n.axis > 2) return bad("BVH node axis out of range");
                 uint32_t wl = 0, wr = 0;
+                const uint32_t media_before = media_walked;
                 if (!walk(n.left, owner, level + 1, wl)) return false;
                 if (n.right != n.left) {
                     if (!walk(n.right, owner, level + 1, wr)) return false;
                 } else {
                     wr = wl;
                 }
+                bvh_impure[idx] = media_walked != media_before;
                 words = FRAME_WORDS_BVH + std::max(wl, wr);
                 return true;
             }
@@ -363,6 +396,107 @@ struct Walker {
 };
 
 uint32_t to_dref(uint32_t ref, uint32_t extra = 0) { return dref(RR_REF_TAG(ref), RR_REF_INDEX(ref), extra); }
+
+// ---------------------------------------------------------- scene program
+// Compiles the ray-independent part of the (already validated) tree into the op array that
+// rrdev::traverse interprets: lists are unrolled in order, instances become transform ops on
+// the current ray space, cuboids become their six rect ops, a medium becomes begin / boundary /
+// mid / boundary / end, and every BVH node (or a medium nested in a medium's boundary) becomes
+// one OP_SUBTREE for the per-lane machine.
+struct ProgramBuilder {
+    const rr_flat_scene& s;
+    std::vector<Op> ops;
+    std::vector<uint32_t> chain;  // instances enclosing the node being emitted, outermost first
+    std::vector<uint32_t> space;  // instances the ops emitted so far have applied to the ray
+    bool in_medium = false;
+
+    static Op make(uint32_t code, uint32_t ref = NONE, float f0 = 0, float f1 = 0, float f2 = 0, float f3 = 0, float f4 = 0,
+                   float f5 = 0) {
+        return Op{code, ref, f0, f1, f2, f3, f4, f5};
+    }
+    void xform(uint32_t ii, bool entering) {
+        const rr_instance& in = s.instances[ii];
+        const uint32_t flag = entering ? OPF_COUNT_VISIT : 0u;
+        if (in.kind == RR_INST_TRANSLATE)
+            ops.push_back(make(OP_TRANSLATE | flag, NONE, in.v[0], in.v[1], in.v[2]));
+        else
+            ops.push_back(make((in.kind == RR_INST_ROTATE_X ? OP_ROT_X : in.kind == RR_INST_ROTATE_Y ? OP_ROT_Y : OP_ROT_Z) | flag,
+                               NONE, in.v[0], in.v[1]));
+    }
+    // Make the ray space of the next op equal to `chain`, always recomputing from the world ray.
+    void ensure_space() {
+        if (space == chain) return;
+        size_t common = 0;
+        while (common < space.size() && common < chain.size() && space[common] == chain[common]) ++common;
+        if (common != space.size()) {  // leaving a space cannot be undone exactly: start again from the world ray
+            ops.push_back(make(OP_RESET));
+            common = 0;
+        }
+        for (size_t k = common; k < chain.size(); ++k) xform(chain[k], false);
+        space = chain;
+    }
+    void rect_op(uint32_t ri) {
+        const rr_rect& r = s.rects[ri];
+        const uint32_t code = r.axis == RR_RECT_XY ? OP_RECT_XY : (r.axis == RR_RECT_XZ ? OP_RECT_XZ : OP_RECT_YZ);
+        ops.push_back(make(code, dref(RR_TAG_RECT, ri), r.a0, r.a1, r.b0, r.b1, r.k));
+    }
+    void emit(uint32_t ref) {
+        const uint32_t tag = RR_REF_TAG(ref), idx = RR_REF_INDEX(ref);
+        switch (tag) {
+            case RR_TAG_LIST: {
+                const rr_list& l = s.lists[idx];
+                for (uint32_t i = 0; i < l.n_children; ++i) emit(s.child_refs[l.first_child + i]);
+                break;
+            }
+            case RR_TAG_INSTANCE:
+                ensure_space();
+                xform(idx, true);
+                chain.push_back(idx);
+                space = chain;
+                emit(s.instances[idx].child);
+                chain.pop_back();
+                break;
+            case RR_TAG_RECT:
+                ensure_space();
+                rect_op(idx);
+                break;
+            case RR_TAG_CUBOID:
+                ensure_space();
+                for (uint32_t i = 0; i < 6; ++i) rect_op(s.cuboids[idx].first_rect + i);
+                break;
+            case RR_TAG_SPHERE: {
+                ensure_space();
+                const rr_sphere& p = s.spheres[idx];
+                ops.push_back(make(OP_SPHERE, dref(RR_TAG_SPHERE, idx), p.center[0], p.center[1], p.center[2], p.radius));
+                break;
+            }
+            case RR_TAG_TRIANGLE:
+            case RR_TAG_MOVING_SPHERE:
+                ensure_space();
+                ops.push_back(make(OP_LEAF_REF, dref(tag, idx)));
+                break;
+            case RR_TAG_MEDIUM:
+                ensure_space();
+                if (in_medium) {  // a medium inside a medium's boundary: whole subtree to the machine
+                    ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
+                    break;
+                }
+                in_medium = true;
+                ops.push_back(make(OP_MED_BEGIN));
+                emit(s.media[idx].boundary);
+                ops.push_back(make(OP_MED_MID));
+                emit(s.media[idx].boundary);
+                ensure_space();  // the free path is measured along the ray in the medium's own space
+                ops.push_back(make(OP_MED_END, dref(tag, idx), s.media[idx].neg_inv_density));
+                in_medium = false;
+                break;
+            default:  // RR_TAG_BVH
+                ensure_space();
+                ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
+                break;
+        }
+    }
+};
 
 template <class T>
 int upload(DeviceBuffers& mem, const std::vector<T>& host, const T** out) {
@@ -492,13 +626,17 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
                                     " words per lane exceeds the LDS available to one workgroup");
 
     // ---- pack
-    std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2);
+    // The traversal machine reads three 16-byte words at every record it visits, whatever the
+    // record's length: the arrays it reads that way end in two words of padding and are never empty.
+    constexpr size_t PAD = 2;
+    std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2 + PAD);
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
         const rr_bvh_node& n = s->bvh_nodes[i];
         bvh[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], u2f(to_dref(n.left, n.axis)));
-        bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, n.has_box ? 1u : 0u)));
+        bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2],
+                                     u2f(to_dref(n.right) | (n.has_box ? BVH_HAS_BOX : 0u) | (wk.bvh_impure[i] ? BVH_IMPURE : 0u)));
     }
-    std::vector<float4> sphere(s->n_spheres);
+    std::vector<float4> sphere(s->n_spheres + PAD);
     std::vector<uint2> sphere_meta(s->n_spheres);
     ctx->id_sphere.resize(s->n_spheres);
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
@@ -507,7 +645,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         sphere_meta[i] = make_uint2(p.material, wk.owner_sphere[i]);
         ctx->id_sphere[i] = p.prim_id;
     }
-    std::vector<float4> msphere(static_cast<size_t>(s->n_moving_spheres) * 3);
+    std::vector<float4> msphere(static_cast<size_t>(s->n_moving_spheres) * 3 + PAD);
     ctx->id_msphere.resize(s->n_moving_spheres);
     for (uint32_t i = 0; i < s->n_moving_spheres; ++i) {
         const rr_moving_sphere& p = s->moving_spheres[i];
@@ -516,7 +654,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         msphere[3 * i + 2] = make_float4(p.radius, u2f(p.material), u2f(wk.owner_msphere[i]), 0.f);
         ctx->id_msphere[i] = p.prim_id;
     }
-    std::vector<float4> rect(static_cast<size_t>(s->n_rects) * 2);
+    std::vector<float4> rect(static_cast<size_t>(s->n_rects) * 2 + PAD);
     ctx->id_rect.resize(s->n_rects);
     for (uint32_t i = 0; i < s->n_rects; ++i) {
         const rr_rect& p = s->rects[i];
@@ -524,7 +662,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         rect[2 * i + 1] = make_float4(p.k, u2f(p.axis), u2f(p.material), u2f(wk.owner_rect[i]));
         ctx->id_rect[i] = p.prim_id;
     }
-    std::vector<float4> tri(static_cast<size_t>(s->n_triangles) * 3);
+    std::vector<float4> tri(static_cast<size_t>(s->n_triangles) * 3 + PAD);
     std::vector<uint2> tri_meta(s->n_triangles);
     ctx->id_tri.resize(s->n_triangles);
     for (uint32_t i = 0; i < s->n_triangles; ++i) {
@@ -535,8 +673,23 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         tri_meta[i] = make_uint2(p.material, wk.owner_tri[i]);
         ctx->id_tri[i] = p.prim_id;
     }
-    std::vector<uint32_t> cuboid(s->n_cuboids);
-    for (uint32_t i = 0; i < s->n_cuboids; ++i) cuboid[i] = s->cuboids[i].first_rect;
+    std::vector<float4> cuboid(static_cast<size_t>(s->n_cuboids) * 2 + PAD);
+    for (uint32_t i = 0; i < s->n_cuboids; ++i) {
+        // Corners of the box, if the six rects are exactly what Cuboid::new (collider.rs:419-426)
+        // makes of two corners; the machine then tests the sides from these 32 bytes alone.
+        if (!wk.seen[RR_TAG_CUBOID][i]) continue;  // not part of the tree: never visited, range never checked
+        const rr_rect* r = &s->rects[s->cuboids[i].first_rect];
+        const float p0[3] = {r[0].a0, r[0].b0, r[1].k}, p1[3] = {r[0].a1, r[0].b1, r[0].k};
+        auto is = [](const rr_rect& q, uint32_t axis, float a0, float a1, float b0, float b1, float k) {
+            const float have[5] = {q.a0, q.a1, q.b0, q.b1, q.k}, want[5] = {a0, a1, b0, b1, k};
+            return q.axis == axis && std::memcmp(have, want, sizeof(have)) == 0;
+        };
+        const bool canonical = is(r[0], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p1[2]) && is(r[1], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p0[2]) &&
+                               is(r[2], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p1[1]) && is(r[3], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p0[1]) &&
+                               is(r[4], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p1[0]) && is(r[5], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p0[0]);
+        cuboid[2 * i] = make_float4(p0[0], p0[1], p0[2], u2f(s->cuboids[i].first_rect));
+        cuboid[2 * i + 1] = make_float4(p1[0], p1[1], p1[2], u2f(canonical ? 1u : 0u));
+    }
     std::vector<uint4> medium(s->n_media);
     ctx->id_medium.resize(s->n_media);
     for (uint32_t i = 0; i < s->n_media; ++i) {
@@ -586,6 +739,13 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevImage> images(s->n_images);
     for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
+    ProgramBuilder pb{*s, {}, {}, {}, false};
+    pb.emit(s->root);
+    pb.ops.push_back(ProgramBuilder::make(OP_END));
+    pb.ops.push_back(ProgramBuilder::make(OP_END));  // the interpreter prefetches one op past the one it runs
+    static_assert(sizeof(Op) == 32, "one op is two 16-byte words");
+    std::vector<uint4> prog(pb.ops.size() * 2);
+    std::memcpy(prog.data(), pb.ops.data(), pb.ops.size() * sizeof(Op));
 
     // ---- upload (replacing any previous scene)
     (void)hipDeviceSynchronize();
@@ -594,26 +754,35 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     DevScene d{};
     DeviceBuffers& mem = ctx->scene_mem;
     int rc = RR_OK;
-    if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &d.sphere_meta)) ||
+    std::vector<DevConst> kc(1);
+    DevConst& k = kc[0];
+    const uint4* prog_dev = nullptr;
+    if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &k.sphere_meta)) ||
         (rc = upload(mem, msphere, &d.msphere)) || (rc = upload(mem, rect, &d.rect)) || (rc = upload(mem, tri, &d.tri)) ||
-        (rc = upload(mem, tri_meta, &d.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
+        (rc = upload(mem, tri_meta, &k.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
         (rc = upload(mem, inst, &d.inst)) || (rc = upload(mem, wk.inst_chain, &d.inst_chain)) || (rc = upload(mem, list, &d.list)) ||
-        (rc = upload(mem, child_refs, &d.child_refs)) || (rc = upload(mem, materials, &d.materials)) ||
-        (rc = upload(mem, textures, &d.textures)) || (rc = upload(mem, perlin_vec, &d.perlin_vec)) ||
-        (rc = upload(mem, perlin_perm, &d.perlin_perm)) || (rc = upload(mem, images, &d.images)) ||
-        (rc = upload(mem, image_bytes, &d.image_bytes))) {
+        (rc = upload(mem, child_refs, &d.child_refs)) || (rc = upload(mem, materials, &k.materials)) ||
+        (rc = upload(mem, textures, &k.textures)) || (rc = upload(mem, perlin_vec, &k.perlin_vec)) ||
+        (rc = upload(mem, perlin_perm, &k.perlin_perm)) || (rc = upload(mem, images, &k.images)) ||
+        (rc = upload(mem, image_bytes, &k.image_bytes)) || (rc = upload(mem, prog, &prog_dev))) {
         mem.release();
         return rc;
     }
-    d.root = to_dref(s->root);
-    d.light_is_xzrect = s->light.is_xzrect ? 1u : 0u;
-    d.light_x0 = s->light.x0;
-    d.light_x1 = s->light.x1;
-    d.light_z0 = s->light.z0;
-    d.light_z1 = s->light.z1;
-    d.light_k = s->light.k;
-    d.cam = s->camera;
-    for (int k = 0; k < 3; ++k) d.background[k] = s->background[k];
+    d.prog = (decltype(d.prog))prog_dev;  // C-style cast: the member is address-space qualified in the device pass
+    k.light_is_xzrect = s->light.is_xzrect ? 1u : 0u;
+    k.light_x0 = s->light.x0;
+    k.light_x1 = s->light.x1;
+    k.light_z0 = s->light.z0;
+    k.light_z1 = s->light.z1;
+    k.light_k = s->light.k;
+    k.cam = s->camera;
+    for (int a = 0; a < 3; ++a) k.background[a] = s->background[a];
+    const DevConst* k_dev = nullptr;
+    if ((rc = upload(mem, kc, &k_dev))) {
+        mem.release();
+        return rc;
+    }
+    d.k = (decltype(d.k))k_dev;
     ctx->sc = d;
     ctx->info = rr_scene_info{};
     ctx->info.stack_words = stack_words;

@@ -136,6 +136,21 @@ def test_intersection_counters_match_oracle(gpu_ctx):
         assert abs(got[k] - want[k]) <= 5e-3 * want[k], (k, got[k], want[k])
 
 
+@pytest.mark.parametrize("name", ["cornell", "spheres", "suzanne", "final"])
+def test_fast_traversal_equals_reference_order_traversal(gpu_ctx, name):
+    """The production kernel leaves out BVH visits that cannot change the result (the re-test of `left`
+    after it missed, collider.rs:555-561, and the second visit of a span-1 node's only child) wherever
+    no constant medium lies below; the counting kernel makes every visit the reference makes.  Both must
+    produce the same bits."""
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=2, max_depth=50, seed=17)
+    fast = gpu_ctx.render(device.make_params(56, 40, 6, **kw))
+    full = gpu_ctx.render(device.make_params(56, 40, 6, flags=abi.FLAG_COUNTERS, **kw))
+    assert np.array_equal(fast["slice_sums"], full["slice_sums"], equal_nan=True)
+    assert np.array_equal(fast["rgb8"], full["rgb8"])
+
+
 # --------------------------------------------------- size-independent properties
 def test_render_is_deterministic_and_slices_compose(gpu_ctx):
     """Bit-identical reruns; rendering slice ranges separately equals rendering them together; a
