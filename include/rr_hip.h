@@ -224,7 +224,14 @@ typedef struct rr_render_params {
     uint32_t flags;             /* RR_FLAG_* */
 } rr_render_params;
 
-#define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests (slower build of the kernel) */
+#define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests; this build of the kernels makes
+                               every BVH visit the reference makes, in its order (slower, same image) */
+/* The library renders with one of two kernel organisations that produce the same bits: a single
+ * persistent kernel (a lane follows its path from camera ray to termination), used for scenes
+ * without BVH nodes, and a wavefront pipeline (traversal and shading kernels over a compacted
+ * queue of live paths), used for scenes with them.  These flags override the choice.       */
+#define RR_FLAG_PERSISTENT 2u
+#define RR_FLAG_WAVEFRONT 4u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */
@@ -290,8 +297,11 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
  *   d_linear     : H × W × 3 f32, Σ over the rendered slices of the NaN-scrubbed
  *                  pixel sums (linear radiance × samples).          Optional.
  *   d_counters   : one rr_counters, ADDED to (caller zeroes it).   Optional.
- * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream) and the
- * call returns without synchronising.                                       */
+ * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream).  The
+ * persistent kernel is enqueued and the call returns without synchronising; the
+ * wavefront pipeline launches a pair of kernels per bounce until no path is left,
+ * which the host learns by synchronising with the stream every few bounces, so
+ * that call returns when the path tracing itself (not the resolve) is complete. */
 int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
                      void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
 

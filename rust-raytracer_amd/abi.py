@@ -19,6 +19,8 @@ INST_TRANSLATE, INST_ROTATE_X, INST_ROTATE_Y, INST_ROTATE_Z = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_GLOSSY, MAT_DIELECTRIC, MAT_ISOTROPIC, MAT_EMISSIVE = 0, 1, 2, 3, 4
 TEX_SOLID, TEX_CHECKERED, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 FLAG_COUNTERS = 1
+FLAG_PERSISTENT = 2
+FLAG_WAVEFRONT = 4
 PERLIN_POINTS = 256
 
 

@@ -413,244 +413,277 @@ __device__ __forceinline__ f3 msphere_center(float4 a, float4 b, float time) {  
 // post-transforms are recomputed once from them in reconstruct_hit().
 //
 // stk addresses this lane's stack: word w lives at stk[w * stride].
+struct Trav {
+    f3 o, d, inv;  // ray in the current space; inv = 1/d, which aabb.rs:39 forms anew in every box test
+    float tmin, tmax;
+    uint32_t cur, node, sp;
+    bool hitf;  // a hit was accepted since the innermost open first-child call or medium probe began
+
+    __device__ __forceinline__ void set_ray(f3 o_, f3 d_) {
+        o = o_;
+        d = d_;
+        inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z);
+    }
+    __device__ __forceinline__ void begin(uint32_t start, f3 o_, f3 d_, float tmin_, float tmax_, uint32_t cur_) {
+        set_ray(o_, d_);
+        tmin = tmin_;
+        tmax = tmax_;
+        cur = cur_;
+        node = start;
+        sp = 0;
+        hitf = false;
+    }
+    __device__ __forceinline__ bool finished() const { return node == NONE; }  // holds between steps only
+};
+
+// What the machine needs only now and then comes through two small providers, so that a kernel
+// can keep it in registers or fetch it on demand:
+//   World: ray(wo, wd) — the ray in world space; time() — the ray's time
+//   Draw:  random()    — the next f32 of the path's random stream
+//
+// One step: evaluate m.node if there is one, then return to callers until one of them names the
+// next node or the outermost call has returned (m.finished()).
+template <bool COUNT, class World, class Draw>
+__device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk,
+                                          uint32_t stride, Counts& cnt) {
+    // ------------------------------------------------ evaluate the node
+    if (m.node != NONE) {
+        const uint32_t node = m.node;
+        const uint32_t tag = dtag(node), idx = didx(node);
+        // One address, three 16-byte loads and one wait for whatever kind of record each lane
+        // is at (every record array is padded by two words, so reading past a short record
+        // is harmless): lanes at BVH nodes and lanes at primitives wait together instead of
+        // one after the other.
+        const float4* rp = sc.bvh;
+        uint32_t roff = 2 * idx;
+        if (tag == RR_TAG_TRIANGLE) rp = sc.tri, roff = 3 * idx;
+        if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
+        if (tag == RR_TAG_RECT) rp = sc.rect;
+        if (tag == RR_TAG_CUBOID) rp = sc.cuboid;
+        if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere, roff = 3 * idx;
+        if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
+        const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
+        m.node = NONE;
+        if (tag == RR_TAG_BVH) {
+            const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
+            bool pass = true;
+            if (right & BVH_HAS_BOX) {
+                if (COUNT) cnt.box_tests++;
+                pass = test_box_inv(q0, q1, m.o, m.inv, m.tmin, m.tmax);
+            }
+            if (pass) {
+                const uint32_t l = left & REF_MASK, r = right & REF_MASK;
+                const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
+                // Below a node without a constant medium every intersect call is a pure function
+                // of (ray, t range): evaluating the same child twice over the same or a smaller
+                // range cannot change the outcome.  The counting build evaluates everything.
+                const bool pure = !COUNT && !(right & BVH_IMPURE);
+                if (pure && l == r) {
+                    m.node = l;  // span-1 node: the second visit repeats the first
+                } else {
+                    uint32_t fw;
+                    if (!dirpos)
+                        fw = l;  // right first; left follows after a hit and after a miss alike
+                    else if (pure)
+                        fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
+                    else
+                        fw = frame_word(FK_BVH2, idx);
+                    stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
+                    m.sp += 1;
+                    m.hitf = false;
+                    m.node = dirpos ? l : r;
+                }
+            }
+        } else if (tag == RR_TAG_SPHERE) {
+            if (COUNT) cnt.sphere_tests++;
+            float t;
+            if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, m.o, m.d, m.tmin, m.tmax, t)) {
+                m.tmax = t;
+                m.cur = node;
+                m.hitf = true;
+            }
+        } else if (tag == RR_TAG_TRIANGLE) {
+            if (COUNT) cnt.tri_tests++;
+            float t;
+            if (test_triangle(q0, q1, q2, m.o, m.d, t)) {
+                m.tmax = t;
+                m.cur = node;
+                m.hitf = true;
+            }
+        } else if (tag == RR_TAG_RECT) {
+            if (COUNT) cnt.rect_tests++;
+            float t, ca, cb;
+            if (test_rect(q0, q1.x, __float_as_uint(q1.y), m.o, m.d, m.tmin, m.tmax, t, ca, cb)) {
+                m.tmax = t;
+                m.cur = node;
+                m.hitf = true;
+            }
+        } else if (tag == RR_TAG_CUBOID) {
+            // six rects as a linear closest-hit list (collider.rs:428-430 → 751-772)
+            const uint32_t first = __float_as_uint(q0.w);
+            if (COUNT) cnt.rect_tests += 6;
+            if (__float_as_uint(q1.w) != 0u) {
+                // the sides are the constructor's (collider.rs:419-426): all six follow from the corners
+                float t;
+                uint32_t side = NONE;
+                if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q1.z, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 0;
+                if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q0.z, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 1;
+                if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q1.y, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 2;
+                if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q0.y, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 3;
+                if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q1.x, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 4;
+                if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q0.x, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 5;
+                if (side != NONE) {
+                    m.cur = dref(RR_TAG_RECT, first + side);
+                    m.hitf = true;
+                }
+            } else {
+                for (uint32_t i = 0; i < 6; ++i) {
+                    const float4 r0 = sc.rect[2 * (first + i)], r1 = sc.rect[2 * (first + i) + 1];
+                    float t, ca, cb;
+                    if (test_rect(r0, r1.x, __float_as_uint(r1.y), m.o, m.d, m.tmin, m.tmax, t, ca, cb)) {
+                        m.tmax = t;
+                        m.cur = dref(RR_TAG_RECT, first + i);
+                        m.hitf = true;
+                    }
+                }
+            }
+        } else if (tag == RR_TAG_MOVING_SPHERE) {
+            if (COUNT) cnt.sphere_tests++;
+            float t;
+            if (test_sphere(msphere_center(q0, q1, world.time()), q2.x, m.o, m.d, m.tmin, m.tmax, t)) {
+                m.tmax = t;
+                m.cur = node;
+                m.hitf = true;
+            }
+        } else if (tag == RR_TAG_LIST) {
+            const uint2 l = sc.list[idx];
+            if (l.y != 0) {
+                stk[m.sp * stride] = l.x + 1;
+                stk[(m.sp + 1) * stride] = frame_word(FK_LIST, idx);
+                m.sp += 2;
+                m.node = sc.child_refs[l.x];
+            }
+        } else if (tag == RR_TAG_INSTANCE) {
+            if (COUNT) cnt.inst_visits++;
+            stk[m.sp * stride] = frame_word(FK_INST, idx);
+            m.sp += 1;
+            f3 o = m.o, d = m.d;
+            inst_apply_ray(sc, idx, o, d);
+            m.set_ray(o, d);
+            m.node = __float_as_uint(sc.inst[2 * idx].y);
+        } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
+            if (COUNT) cnt.inst_visits++;
+            stk[m.sp * stride] = __float_as_uint(m.tmin);
+            stk[(m.sp + 1) * stride] = __float_as_uint(m.tmax);
+            stk[(m.sp + 2) * stride] = m.cur;
+            stk[(m.sp + 3) * stride] = 0u;
+            stk[(m.sp + 4) * stride] = frame_word(FK_MED1, idx) | (m.hitf ? FW_FLAG : 0u);
+            m.sp += 5;
+            m.tmin = -kF32Max;
+            m.tmax = kF32Max;
+            m.hitf = false;
+            m.node = sc.medium[idx].x;
+        }
+    }
+    // ------------------------------------------- return to the callers
+    while (m.node == NONE && m.sp != 0) {
+        const uint32_t fw = stk[(m.sp - 1) * stride];
+        const uint32_t kind = dtag(fw), idx = didx(fw);
+        if (kind <= RR_TAG_LIST) {
+            // collider.rs:546-580 after the first child came back: the frame names what comes next
+            m.sp -= 1;
+            const bool first_hit = m.hitf;
+            m.hitf = first_hit || (fw & FW_FLAG);
+            m.node = (!first_hit && (fw & FW_MISS_NONE)) ? NONE : (fw & REF_MASK);
+        } else if (kind == FK_BVH2) {
+            // left went first: right with t_max = the hit's t, or left once more after a miss
+            m.sp -= 1;
+            const bool first_hit = m.hitf;
+            m.hitf = first_hit || (fw & FW_FLAG);
+            m.node = __float_as_uint(first_hit ? sc.bvh[2 * idx + 1].w : sc.bvh[2 * idx].w) & REF_MASK;
+        } else if (kind == FK_LIST) {
+            const uint32_t pos = stk[(m.sp - 2) * stride];
+            const uint2 l = sc.list[idx];
+            if (pos < l.x + l.y) {
+                stk[(m.sp - 2) * stride] = pos + 1;
+                m.node = sc.child_refs[pos];
+            } else {
+                m.sp -= 2;
+            }
+        } else if (kind == FK_INST) {
+            m.sp -= 1;
+            const uint32_t depth = inst_depth(sc, idx);
+            f3 wo, wd, o, d;
+            world.ray(wo, wd);
+            localize(sc, idx, depth - 1, wo, wd, o, d);  // back to the enclosing space, recomputed from the world ray
+            m.set_ray(o, d);
+        } else if (kind == FK_MED1) {
+            if (!m.hitf) {
+                m.tmin = __uint_as_float(stk[(m.sp - 5) * stride]);
+                m.tmax = __uint_as_float(stk[(m.sp - 4) * stride]);
+                m.cur = stk[(m.sp - 3) * stride];
+                m.hitf = (fw & FW_FLAG) != 0u;
+                m.sp -= 5;
+            } else {  // second probe over (t1 + 0.0001, f32::MAX), collider.rs:443
+                const float t1 = m.tmax;
+                stk[(m.sp - 2) * stride] = __float_as_uint(t1);
+                stk[(m.sp - 1) * stride] = frame_word(FK_MED2, idx) | (fw & FW_FLAG);
+                m.tmin = t1 + 0.0001f;
+                m.tmax = kF32Max;
+                m.hitf = false;
+                m.node = sc.medium[idx].x;
+            }
+        } else {  // FK_MED2
+            const bool found = m.hitf;
+            float t2 = m.tmax;
+            float t1 = __uint_as_float(stk[(m.sp - 2) * stride]);
+            m.tmin = __uint_as_float(stk[(m.sp - 5) * stride]);
+            m.tmax = __uint_as_float(stk[(m.sp - 4) * stride]);
+            m.cur = stk[(m.sp - 3) * stride];
+            m.hitf = (fw & FW_FLAG) != 0u;
+            m.sp -= 5;
+            if (found) {  // collider.rs:448-474
+                if (t1 < m.tmin) t1 = m.tmin;
+                if (t2 > m.tmax) t2 = m.tmax;
+                if (t1 < t2) {
+                    if (t1 < 0.0f) t1 = 0.0f;
+                    const float ray_length = len3(m.d);
+                    const float dist_inside = (t2 - t1) * ray_length;
+                    const float hit_dist = __uint_as_float(sc.medium[idx].y) * log10f(draw.random());
+                    if (!(hit_dist > dist_inside)) {
+                        m.tmax = t1 + hit_dist / ray_length;
+                        m.cur = dref(RR_TAG_MEDIUM, idx);
+                        m.hitf = true;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Providers for a kernel that holds the world ray and the path's generator in registers.
+struct WorldInRegs {
+    f3 wo, wd;
+    float t;
+    __device__ __forceinline__ void ray(f3& o, f3& d) const {
+        o = wo;
+        d = wd;
+    }
+    __device__ __forceinline__ float time() const { return t; }
+};
+
+// The whole recursive call for `start`, to completion.
 template <bool COUNT>
 __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 wo, f3 wd, f3 o, f3 d, float time, float tmin,
                                         float& tmax_io, uint32_t& cur_io, Rng& rng, uint32_t* stk, uint32_t stride, Counts& cnt) {
-    float tmax = tmax_io;
-    uint32_t cur = cur_io;
-    uint32_t sp = 0;
-    uint32_t node = start;
-    bool hitf = false;  // a hit was accepted since the innermost open first-child call or medium probe began
-    // aabb.rs:39 forms 1/direction anew in every box test; the quotient is the same every time, so
-    // it is formed once per ray space here
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    for (;;) {
-        // ------------------------------------------------ evaluate `node`
-        if (node != NONE) {
-            const uint32_t tag = dtag(node), idx = didx(node);
-            // One address, three 16-byte loads and one wait for whatever kind of record each lane
-            // is at (every record array is padded by two words, so reading past a short record
-            // is harmless): lanes at BVH nodes and lanes at primitives wait together instead of
-            // one after the other.
-            const float4* rp = sc.bvh;
-            uint32_t roff = 2 * idx;
-            if (tag == RR_TAG_TRIANGLE) rp = sc.tri, roff = 3 * idx;
-            if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
-            if (tag == RR_TAG_RECT) rp = sc.rect;
-            if (tag == RR_TAG_CUBOID) rp = sc.cuboid;
-            if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere, roff = 3 * idx;
-            if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
-            const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
-            if (tag == RR_TAG_BVH) {
-                const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
-                bool pass = true;
-                if (right & BVH_HAS_BOX) {
-                    if (COUNT) cnt.box_tests++;
-                    pass = test_box_inv(q0, q1, o, inv, tmin, tmax);
-                }
-                if (pass) {
-                    const uint32_t l = left & REF_MASK, r = right & REF_MASK;
-                    const bool dirpos = comp(d, dextra(left)) >= 0.0f;
-                    // Below a node without a constant medium every intersect call is a pure function
-                    // of (ray, t range): evaluating the same child twice over the same or a smaller
-                    // range cannot change the outcome.  The counting build evaluates everything.
-                    const bool pure = !COUNT && !(right & BVH_IMPURE);
-                    if (pure && l == r) {
-                        node = l;  // span-1 node: the second visit repeats the first
-                    } else {
-                        uint32_t fw;
-                        if (!dirpos)
-                            fw = l;  // right first; left follows after a hit and after a miss alike
-                        else if (pure)
-                            fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
-                        else
-                            fw = frame_word(FK_BVH2, idx);
-                        stk[sp * stride] = fw | (hitf ? FW_FLAG : 0u);
-                        sp += 1;
-                        hitf = false;
-                        node = dirpos ? l : r;
-                    }
-                } else {
-                    node = NONE;
-                }
-            } else if (tag == RR_TAG_SPHERE) {
-                if (COUNT) cnt.sphere_tests++;
-                float t;
-                if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, o, d, tmin, tmax, t)) {
-                    tmax = t;
-                    cur = node;
-                    hitf = true;
-                }
-                node = NONE;
-            } else if (tag == RR_TAG_TRIANGLE) {
-                if (COUNT) cnt.tri_tests++;
-                float t;
-                if (test_triangle(q0, q1, q2, o, d, t)) {
-                    tmax = t;
-                    cur = node;
-                    hitf = true;
-                }
-                node = NONE;
-            } else if (tag == RR_TAG_RECT) {
-                if (COUNT) cnt.rect_tests++;
-                float t, ca, cb;
-                if (test_rect(q0, q1.x, __float_as_uint(q1.y), o, d, tmin, tmax, t, ca, cb)) {
-                    tmax = t;
-                    cur = node;
-                    hitf = true;
-                }
-                node = NONE;
-            } else if (tag == RR_TAG_CUBOID) {
-                // six rects as a linear closest-hit list (collider.rs:428-430 → 751-772)
-                const uint32_t first = __float_as_uint(q0.w);
-                if (COUNT) cnt.rect_tests += 6;
-                if (__float_as_uint(q1.w) != 0u) {
-                    // the sides are the constructor's (collider.rs:419-426): all six follow from the corners
-                    float t;
-                    uint32_t side = NONE;
-                    if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q1.z, o, d, tmin, tmax, t)) tmax = t, side = 0;
-                    if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q0.z, o, d, tmin, tmax, t)) tmax = t, side = 1;
-                    if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q1.y, o, d, tmin, tmax, t)) tmax = t, side = 2;
-                    if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q0.y, o, d, tmin, tmax, t)) tmax = t, side = 3;
-                    if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q1.x, o, d, tmin, tmax, t)) tmax = t, side = 4;
-                    if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q0.x, o, d, tmin, tmax, t)) tmax = t, side = 5;
-                    if (side != NONE) {
-                        cur = dref(RR_TAG_RECT, first + side);
-                        hitf = true;
-                    }
-                } else {
-                    for (uint32_t i = 0; i < 6; ++i) {
-                        const float4 r0 = sc.rect[2 * (first + i)], r1 = sc.rect[2 * (first + i) + 1];
-                        float t, ca, cb;
-                        if (test_rect(r0, r1.x, __float_as_uint(r1.y), o, d, tmin, tmax, t, ca, cb)) {
-                            tmax = t;
-                            cur = dref(RR_TAG_RECT, first + i);
-                            hitf = true;
-                        }
-                    }
-                }
-                node = NONE;
-            } else if (tag == RR_TAG_MOVING_SPHERE) {
-                if (COUNT) cnt.sphere_tests++;
-                float t;
-                if (test_sphere(msphere_center(q0, q1, time), q2.x, o, d, tmin, tmax, t)) {
-                    tmax = t;
-                    cur = node;
-                    hitf = true;
-                }
-                node = NONE;
-            } else if (tag == RR_TAG_LIST) {
-                const uint2 l = sc.list[idx];
-                if (l.y == 0) {
-                    node = NONE;
-                } else {
-                    stk[sp * stride] = l.x + 1;
-                    stk[(sp + 1) * stride] = frame_word(FK_LIST, idx);
-                    sp += 2;
-                    node = sc.child_refs[l.x];
-                }
-            } else if (tag == RR_TAG_INSTANCE) {
-                if (COUNT) cnt.inst_visits++;
-                stk[sp * stride] = frame_word(FK_INST, idx);
-                sp += 1;
-                inst_apply_ray(sc, idx, o, d);
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                node = __float_as_uint(sc.inst[2 * idx].y);
-            } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
-                if (COUNT) cnt.inst_visits++;
-                stk[sp * stride] = __float_as_uint(tmin);
-                stk[(sp + 1) * stride] = __float_as_uint(tmax);
-                stk[(sp + 2) * stride] = cur;
-                stk[(sp + 3) * stride] = 0u;
-                stk[(sp + 4) * stride] = frame_word(FK_MED1, idx) | (hitf ? FW_FLAG : 0u);
-                sp += 5;
-                tmin = -kF32Max;
-                tmax = kF32Max;
-                hitf = false;
-                node = sc.medium[idx].x;
-            }
-        }
-        // ------------------------------------------- return to the callers
-        bool done = false;
-        while (node == NONE) {
-            if (sp == 0) {
-                done = true;
-                break;
-            }
-            const uint32_t fw = stk[(sp - 1) * stride];
-            const uint32_t kind = dtag(fw), idx = didx(fw);
-            if (kind <= RR_TAG_LIST) {
-                // collider.rs:546-580 after the first child came back: the frame names what comes next
-                sp -= 1;
-                const bool first_hit = hitf;
-                hitf = first_hit || (fw & FW_FLAG);
-                node = (!first_hit && (fw & FW_MISS_NONE)) ? NONE : (fw & REF_MASK);
-            } else if (kind == FK_BVH2) {
-                // left went first: right with t_max = the hit's t, or left once more after a miss
-                sp -= 1;
-                const bool first_hit = hitf;
-                hitf = first_hit || (fw & FW_FLAG);
-                node = __float_as_uint(first_hit ? sc.bvh[2 * idx + 1].w : sc.bvh[2 * idx].w) & REF_MASK;
-            } else if (kind == FK_LIST) {
-                const uint32_t pos = stk[(sp - 2) * stride];
-                const uint2 l = sc.list[idx];
-                if (pos < l.x + l.y) {
-                    stk[(sp - 2) * stride] = pos + 1;
-                    node = sc.child_refs[pos];
-                } else {
-                    sp -= 2;
-                }
-            } else if (kind == FK_INST) {
-                sp -= 1;
-                const uint32_t depth = inst_depth(sc, idx);
-                localize(sc, idx, depth - 1, wo, wd, o, d);  // back to the enclosing space, recomputed from the world ray
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            } else if (kind == FK_MED1) {
-                if (!hitf) {
-                    tmin = __uint_as_float(stk[(sp - 5) * stride]);
-                    tmax = __uint_as_float(stk[(sp - 4) * stride]);
-                    cur = stk[(sp - 3) * stride];
-                    hitf = (fw & FW_FLAG) != 0u;
-                    sp -= 5;
-                } else {  // second probe over (t1 + 0.0001, f32::MAX), collider.rs:443
-                    const float t1 = tmax;
-                    stk[(sp - 2) * stride] = __float_as_uint(t1);
-                    stk[(sp - 1) * stride] = frame_word(FK_MED2, idx) | (fw & FW_FLAG);
-                    tmin = t1 + 0.0001f;
-                    tmax = kF32Max;
-                    hitf = false;
-                    node = sc.medium[idx].x;
-                }
-            } else {  // FK_MED2
-                const bool found = hitf;
-                float t2 = tmax;
-                float t1 = __uint_as_float(stk[(sp - 2) * stride]);
-                tmin = __uint_as_float(stk[(sp - 5) * stride]);
-                tmax = __uint_as_float(stk[(sp - 4) * stride]);
-                cur = stk[(sp - 3) * stride];
-                hitf = (fw & FW_FLAG) != 0u;
-                sp -= 5;
-                if (found) {  // collider.rs:448-474
-                    if (t1 < tmin) t1 = tmin;
-                    if (t2 > tmax) t2 = tmax;
-                    if (t1 < t2) {
-                        if (t1 < 0.0f) t1 = 0.0f;
-                        const float ray_length = len3(d);
-                        const float dist_inside = (t2 - t1) * ray_length;
-                        const float hit_dist = __uint_as_float(sc.medium[idx].y) * log10f(rng.random());
-                        if (!(hit_dist > dist_inside)) {
-                            tmax = t1 + hit_dist / ray_length;
-                            cur = dref(RR_TAG_MEDIUM, idx);
-                            hitf = true;
-                        }
-                    }
-                }
-            }
-        }
-        if (done) break;
-    }
-    tmax_io = tmax;
-    cur_io = cur;
+    Trav m;
+    m.begin(start, o, d, tmin, tmax_io, cur_io);
+    const WorldInRegs world{wo, wd, time};
+    do {
+        trav_step<COUNT>(sc, m, world, rng, stk, stride, cnt);
+    } while (!m.finished());
+    tmax_io = m.tmax;
+    cur_io = m.cur;
 }
 
 // ------------------------------------------------- wave-uniform traversal

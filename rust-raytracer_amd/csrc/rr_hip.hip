@@ -228,6 +228,8 @@ __global__ void __launch_bounds__(256) k_cast_u8(const float* __restrict__ src, 
     dst[e] = v;
 }
 
+#include "rr_wavefront.h"
+
 // ============================================================ host side
 namespace {
 
@@ -267,6 +269,14 @@ struct rr_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int max_dynamic_lds = 0;
+    // wavefront renderer: whether the scene has BVH subtrees, its root for the traversal machine,
+    // and a grow-only workspace (path state, two queues, queue controls) with a pinned word the
+    // host polls the live-path count through
+    bool has_subtrees = false;
+    uint32_t root = NONE;
+    void* wf_mem = nullptr;
+    size_t wf_bytes = 0;
+    uint32_t* wf_host_count = nullptr;
 };
 
 namespace {
@@ -532,6 +542,99 @@ int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid
     return RR_OK;
 }
 
+int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t n_sl, uint32_t spt, void* d_slice_sums, void* d_resolved,
+                   void* d_linear, hipStream_t stream) {
+    (void)ctx;
+    if (d_resolved || d_linear) {
+        const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
+        const uint32_t g = static_cast<uint32_t>((n_elems + 255u) / 256u);
+        hipLaunchKernelGGL(k_resolve, dim3(g), dim3(256), 0, stream, static_cast<const float*>(d_slice_sums), n_sl, n_elems,
+                           1.0f / static_cast<float>(spt), static_cast<float>(p->n_slices), static_cast<float*>(d_resolved),
+                           static_cast<float*>(d_linear));
+        HIP_TRY(hipGetLastError());
+    }
+    return RR_OK;
+}
+
+// The wavefront renderer for the slices of one pass (a.n_slots slots, absolute first slice
+// a.slice_first): batches of samples, each a bounce loop of traversal and shading launches that
+// ends when no path is left, followed by the in-order accumulation of the batch.  How many
+// bounces a batch takes is only known on the device, so the host reads the live-path count back
+// every few bounces and this function returns when the last batch's paths have ended.
+int render_wavefront(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream) {
+    // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path); the
+    // short low-occupancy tail at the end of a bounce loop is paid once per batch.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 2), static_cast<size_t>(1) << 20);
+    uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(budget / (80u * static_cast<uint64_t>(a.n_slots)), (1ull << 31) / a.n_slots));
+    batch = std::min<uint64_t>(batch, std::max(a.spt, 1u));
+    const size_t n = static_cast<size_t>(a.n_slots) * batch;
+    auto align = [](size_t v) { return (v + 255u) & ~static_cast<size_t>(255u); };
+    const size_t off_o = 0, off_d = off_o + align(n * 16), off_t = off_d + align(n * 16), off_h = off_t + align(n * 16),
+                 off_q0 = off_h + align(n * 16), off_q1 = off_q0 + align(n * 4), off_ctl = off_q1 + align(n * 4),
+                 need = off_ctl + align(3 * sizeof(WfCtl));
+    if (need > ctx->wf_bytes) {
+        if (ctx->wf_mem) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipFree(ctx->wf_mem));
+            ctx->wf_mem = nullptr;
+            ctx->wf_bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&ctx->wf_mem, need));
+        ctx->wf_bytes = need;
+    }
+    if (!ctx->wf_host_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_count), 64, hipHostMallocDefault));
+    char* base = static_cast<char*>(ctx->wf_mem);
+    WfState st{reinterpret_cast<float4*>(base + off_o), reinterpret_cast<float4*>(base + off_d), reinterpret_cast<float4*>(base + off_t),
+               reinterpret_cast<uint4*>(base + off_h)};
+    uint32_t* queue[2] = {reinterpret_cast<uint32_t*>(base + off_q0), reinterpret_cast<uint32_t*>(base + off_q1)};
+    WfCtl* ctl = reinterpret_cast<WfCtl*>(base + off_ctl);
+
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    const void* kernel = count ? reinterpret_cast<const void*>(&k_wf_traverse<true>) : reinterpret_cast<const void*>(&k_wf_traverse<false>);
+    int grid_full = 0;
+    if (int rc = launch_dims(ctx, lds, kernel, &grid_full)) return rc;
+    const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
+
+    constexpr uint32_t POLL_EVERY = 8;
+    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
+        a.s0 = s0;
+        a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        if (a.n_paths != 0) {
+            const uint32_t path_blocks = (a.n_paths + 255u) / 256u;
+            hipLaunchKernelGGL(k_wf_init, dim3(path_blocks), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
+            HIP_TRY(hipGetLastError());
+            uint32_t live = a.n_paths;  // upper bound of the queue length, refreshed at every poll
+            // a path ends at the latest in the ray_color call that finds its depth used up (render.rs:16)
+            for (uint32_t it = 0; it <= a.max_depth; ++it) {
+                WfCtl *c_in = ctl + it % 3u, *c_out = ctl + (it + 1u) % 3u, *c_clear = ctl + (it + 2u) % 3u;
+                const uint32_t* q_in = queue[it & 1u];
+                uint32_t* q_out = queue[(it + 1u) & 1u];
+                const uint32_t live_blocks = (live + 255u) / 256u;
+                const uint32_t grid_t = std::min<uint32_t>(static_cast<uint32_t>(grid_full), live_blocks);
+                const uint32_t grid_s = std::min<uint32_t>(live_blocks, static_cast<uint32_t>(ctx->n_cus) * 16u);
+                if (count)
+                    hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
+                else
+                    hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
+                hipLaunchKernelGGL(k_wf_shade, dim3(grid_s), dim3(256), 0, stream, ctx->sc, a, st, q_in, c_in, q_out, c_out, c_clear, counters);
+                HIP_TRY(hipGetLastError());
+                if ((it + 1u) % POLL_EVERY == 0 && it != a.max_depth) {
+                    HIP_TRY(hipMemcpyAsync(ctx->wf_host_count, &c_out->count, 4, hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    live = *ctx->wf_host_count;
+                    if (live == 0) break;
+                }
+            }
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
+        HIP_TRY(hipGetLastError());
+        if (a.spt == 0) break;
+    }
+    return RR_OK;
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -576,6 +679,8 @@ int rr_context_destroy(rr_context* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     ctx->scene_mem.release();
+    if (ctx->wf_mem) (void)hipFree(ctx->wf_mem);
+    if (ctx->wf_host_count) (void)hipHostFree(ctx->wf_host_count);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -789,6 +894,9 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.max_inst_depth = wk.max_inst_depth;
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
+    ctx->has_subtrees = false;
+    for (const Op& op : pb.ops) ctx->has_subtrees |= (op.code & 0xFFu) == OP_SUBTREE;
+    ctx->root = to_dref(s->root);
     ctx->has_scene = true;
     return RR_OK;
 }
@@ -873,6 +981,35 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     const uint32_t n_sl = p->slice_end - p->slice_begin;
     const uint32_t spt = p->samples_per_pixel / p->n_slices;
     const bool count = (p->flags & RR_FLAG_COUNTERS) != 0;
+    if ((p->flags & RR_FLAG_PERSISTENT) && (p->flags & RR_FLAG_WAVEFRONT))
+        return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT and RR_FLAG_WAVEFRONT exclude each other");
+    const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->has_subtrees && !(p->flags & RR_FLAG_PERSISTENT));
+    if (wavefront) {
+        const uint64_t n_pixels = static_cast<uint64_t>(p->width) * p->height;
+        if (n_pixels > (1ull << 30)) return fail(RR_E_LIMIT, "rr_render_device: more than 2^30 pixels in one wavefront pass");
+        WfArgs w{};
+        w.width = p->width;
+        w.height = p->height;
+        w.n_pixels = static_cast<uint32_t>(n_pixels);
+        w.spt = spt;
+        w.max_depth = p->max_depth;
+        w.sample_offset = p->sample_offset;
+        w.seed = p->seed;
+        // slices go through in groups of at most 2^27 slots (72 bytes of path state and queues each)
+        const uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (1ull << 27) / n_pixels));
+        HIP_TRY(hipEventRecord(ctx->ev0, stream));
+        for (uint32_t s0 = 0; s0 < n_sl; s0 += group) {
+            const uint32_t here = std::min(group, n_sl - s0);
+            w.n_slots = static_cast<uint32_t>(here * n_pixels);
+            w.slice_first = p->slice_begin + s0;
+            w.slice_out = s0;
+            if (int rc = render_wavefront(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
+                return rc;
+        }
+        HIP_TRY(hipEventRecord(ctx->ev1, stream));
+        ctx->timed = true;
+        return resolve_slices(ctx, p, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
+    }
     const void* kernel = count ? reinterpret_cast<const void*>(&k_render<true>) : reinterpret_cast<const void*>(&k_render<false>);
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     int grid = 0;
@@ -908,15 +1045,7 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     }
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
-    if (d_resolved || d_linear) {
-        const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
-        const uint32_t g = static_cast<uint32_t>((n_elems + 255u) / 256u);
-        hipLaunchKernelGGL(k_resolve, dim3(g), dim3(256), 0, stream, static_cast<const float*>(d_slice_sums), n_sl, n_elems,
-                           1.0f / static_cast<float>(spt), static_cast<float>(p->n_slices), static_cast<float*>(d_resolved),
-                           static_cast<float*>(d_linear));
-        HIP_TRY(hipGetLastError());
-    }
-    return RR_OK;
+    return resolve_slices(ctx, p, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
 }
 
 int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uint64_t n, void* hip_stream) {

@@ -151,6 +151,29 @@ def test_fast_traversal_equals_reference_order_traversal(gpu_ctx, name):
     assert np.array_equal(fast["rgb8"], full["rgb8"])
 
 
+@pytest.mark.parametrize("name", ["cornell", "spheres", "suzanne", "final"])
+def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
+    """The two kernel organisations (one persistent kernel; traversal + shading kernels over a queue of
+    live paths) key every random stream and order every f32 sum alike: same bits, same counters."""
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=3, max_depth=12, seed=23)
+    for extra in (0, abi.FLAG_COUNTERS):
+        one = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_PERSISTENT | extra, **kw))
+        two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT | extra, **kw))
+        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
+        assert np.array_equal(one["rgb8"], two["rgb8"])
+        assert one["counters"] == two["counters"]
+    # a slice range, a sample offset and zero depth go through the same bookkeeping
+    for kw2 in (dict(slice_begin=1, slice_end=3), dict(sample_offset=40), dict(max_depth=0), dict(max_depth=1)):
+        args = dict(kw)
+        args.update(kw2)
+        one = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_PERSISTENT, **args))
+        two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT, **args))
+        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True), kw2
+        assert one["counters"] == two["counters"]
+
+
 # --------------------------------------------------- size-independent properties
 def test_render_is_deterministic_and_slices_compose(gpu_ctx):
     """Bit-identical reruns; rendering slice ranges separately equals rendering them together; a
