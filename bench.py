@@ -103,7 +103,7 @@ def main():
     import numpy as np
     import torch
     import rust_raytracer_amd  # noqa: F401
-    from rust_raytracer_amd import device, host
+    from rust_raytracer_amd import device, host, multi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,8 +128,7 @@ def main():
 
     # One render_multi call with world*K slices and world*spp samples; this rank renders slices
     # [rank*K, (rank+1)*K): spp samples per pixel per GPU whatever the world size.
-    p = device.make_params(W, H, spp * world, n_slices=K * world, max_depth=depth, seed=args.seed,
-                           slice_begin=rank * K, slice_end=(rank + 1) * K)
+    p = multi.rank_params(W, H, spp, K, depth, args.seed, rank, world)
     spt = (spp * world) // (K * world)
     dev = torch.device("cuda", local_rank)
     slice_sums = torch.empty((K, H, W, 3), dtype=torch.float32, device=dev)
@@ -141,9 +140,7 @@ def main():
 
     def step():
         ctx.render_device(p, slice_sums.data_ptr(), resolved.data_ptr(), linear.data_ptr(), counters.data_ptr(), stream)
-        if dist is not None:
-            dist.reduce(resolved, dst=0)
-            dist.reduce(linear, dst=0)
+        multi.reduce_images(dist, (resolved, linear))
         if rank == 0:
             ctx.cast_u8_device(resolved.data_ptr(), rgb8.data_ptr(), resolved.numel(), stream)
 
@@ -195,6 +192,10 @@ def main():
         rays_per_launch = int(counts_rank[1]) / args.steps
         samples_per_launch = int(counts_rank[0]) / args.steps
         k_ms = float(np.mean(kernel_ms))
+        # scenes without BVH nodes are one launch of the persistent kernel; scenes with them go through the
+        # wavefront pipeline, whose launches (two per bounce) the HIP events bracket as a whole
+        kernel_name = ("wavefront pipeline: k_wf_init + (k_wf_traverse<false> + k_wf_shade) per bounce + k_wf_accumulate"
+                       if info["wavefront"] else "k_render<false>")
         alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
@@ -216,7 +217,7 @@ def main():
             "rays_per_sample": round(total_rays / max(1, total_samples), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_render<false>", "kernel_ms": round(k_ms, 3),
+                         "kernel": kernel_name, "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_ray": round(bpr, 2), "rays_per_launch": int(rays_per_launch),
                          "per_ray": {k: round(cdict[k] / max(1, cdict["rays"]), 3) for k in names[2:]}},
             "valu": {"flops_per_ray": round(fpr, 1), "achieved_tflops": round(fpr * rays_per_launch / (k_ms * 1e-3) / 1e12, 3),

@@ -259,7 +259,7 @@ typedef struct rr_scene_info {
     uint32_t max_inst_depth; /* deepest instance nesting                 */
     uint64_t device_bytes;   /* bytes of scene data resident in HBM      */
     uint32_t n_prims;        /* spheres + moving spheres + rects + triangles */
-    uint32_t reserved;
+    uint32_t wavefront;      /* 1: rendered by the wavefront pipeline unless RR_FLAG_PERSISTENT is set (the scene has BVH nodes) */
 } rr_scene_info;
 
 typedef struct rr_context rr_context;

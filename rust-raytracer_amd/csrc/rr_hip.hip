@@ -897,6 +897,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->has_subtrees = false;
     for (const Op& op : pb.ops) ctx->has_subtrees |= (op.code & 0xFFu) == OP_SUBTREE;
     ctx->root = to_dref(s->root);
+    ctx->info.wavefront = ctx->has_subtrees ? 1u : 0u;
     ctx->has_scene = true;
     return RR_OK;
 }

@@ -78,6 +78,14 @@ def render(flat, params, n_threads=8, counters=False):
     return dict(slice_sums=ss, resolved=res, linear=lin, rgb8=rgb, counters=cnt.as_dict())
 
 
+def cast_u8(resolved):
+    """The saturating `as u8` of render.rs:156-159 on a summed image."""
+    res = np.ascontiguousarray(resolved, dtype=np.float32)
+    rgb = np.zeros(res.shape, dtype=np.uint8)
+    lib().rro_cast_u8(fptr(res), rgb.ctypes.data_as(C.POINTER(C.c_uint8)), res.size)
+    return rgb
+
+
 def camera_rays(flat, params, pixels, sample=0):
     """Camera rays the renderer would shoot for (i, j_from_bottom) pixels."""
     out = np.zeros((len(pixels), 7), dtype=np.float32)
