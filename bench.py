@@ -198,13 +198,17 @@ def main():
                        if info["wavefront"] else "k_render<false>")
         alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes kept under profiles/ (bytes per sample there, times this launch's samples)
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             try:
-                traffic = json.load(open(pmc_path)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                per_sample = json.load(open(path)).get(args.workload, {}).get("hbm_bytes_per_sample")
             except Exception:
-                traffic = None
+                per_sample = None
+            if per_sample is not None:
+                traffic = round(per_sample * samples_per_launch)
+                break
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,

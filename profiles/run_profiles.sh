@@ -1,26 +1,29 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round on the GPU box:
-#   1. kernel trace + stats of the default bench.py run (the kernel's average duration must agree
-#      with bench.py's own HIP-event timing);
-#   2. PMC passes, one rocprofv3 run each (counters are not split over passes automatically),
-#      on a shorter run of the same workload.
-# Usage (from the repo root, on the GPU box):  bash profiles/run_profiles.sh <tag> [workload]
-# Output goes to gpurun_out/prof_<tag>/; profiles/summarize.py turns it into profiles/<tag>_*.{md,json}.
+# Collects the rocprofv3 evidence for one workload on the GPU box:
+#   1. kernel trace + stats of a bench.py run (the kernels' durations must agree with bench.py's own
+#      HIP-event timing);
+#   2. PMC passes, one rocprofv3 run each (counters are not split over passes automatically), on a
+#      one-step run of the same workload.
+# Usage (from the repo root, on the GPU box):  bash profiles/run_profiles.sh <tag> [workload] [spp]
+# Output goes to gpurun_out/prof_<tag>_<workload>/; profiles/summarize.py turns it into profiles/<tag>_<workload>_*.
 set -u
 TAG=${1:-r1}
 WORKLOAD=${2:-cornell}
+SPP=${3:-0}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/prof_$TAG
+OUT=$ROOT/gpurun_out/prof_${TAG}_$WORKLOAD
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python3 "$ROOT/bench.py" --workload "$WORKLOAD" --steps 3 --warmup 1 --no-cpu > "$OUT/bench_under_trace.json" 2> "$OUT/bench_under_trace.err" || { echo "trace pass failed"; exit 1; }
+    python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$SPP" --steps 3 --warmup 1 --no-cpu > "$OUT/bench_under_trace.json" 2> "$OUT/bench_under_trace.err" || { echo "trace pass failed"; exit 1; }
+echo "trace ok"
 
 pass() {
     name=$1; shift
     timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
-        python3 "$ROOT/bench.py" --workload "$WORKLOAD" --steps 1 --warmup 0 --spp 96 --no-cpu > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || { echo "pmc pass $name failed"; exit 1; }
+        python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$SPP" --steps 1 --warmup 0 --no-cpu > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || { echo "pmc pass $name failed"; exit 1; }
     echo "pass $name ok"
 }
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_BRANCH &&
