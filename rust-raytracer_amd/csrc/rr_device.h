@@ -17,8 +17,8 @@ namespace rrdev {
 
 // ------------------------------------------------------------ packed refs
 // Device refs: index in bits 25..0, tag in bits 29..26, two spare bits 31..30.
-// In a BVH node the spare bits of `left` hold the split axis and those of `right` two flags
-// (BVH_HAS_BOX, BVH_IMPURE), so a node is exactly two 16-byte loads.
+// In a BVH node the spare bits of `left` hold the split axis and those of `right` the node's
+// class (BVH_CLASS_*), so a node is exactly two 16-byte loads.
 constexpr uint32_t IDX_BITS = 26;
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -32,8 +32,15 @@ __host__ __device__ inline uint32_t dextra(uint32_t r) { return r >> 30; }
 constexpr uint32_t MAX_CHAIN = 8;  // deepest instance nesting the device layout holds
 
 constexpr uint32_t REF_MASK = (1u << 30) - 1u;
-constexpr uint32_t BVH_HAS_BOX = 1u << 30;  // in a node's `right`: the node has a bounding box
-constexpr uint32_t BVH_IMPURE = 1u << 31;   // in a node's `right`: a constant medium (which draws random numbers) lies below
+// Spare bits of a node's `right`: how the production kernels may treat the node.
+//   NO_BOX      no bounding box: both children are always visited (collider.rs:538-541)
+//   REFERENCE   the reference's box test decides, every visit is made in the reference's order
+//   CULL_RANGE  no constant medium below and the box holds everything below: a ray whose segment
+//               [t_min, t_max] misses the box (grown by the scene's margin) cannot be accepted below
+//   CULL_ANY_T  the same with triangles below, which accept any t >= 0 (collider.rs:627): the
+//               segment is [0, inf)
+// In the last two classes every intersect call below is a pure function of (ray, t range).
+constexpr uint32_t BVH_CLASS_NO_BOX = 0, BVH_CLASS_REFERENCE = 1, BVH_CLASS_CULL_RANGE = 2, BVH_CLASS_CULL_ANY_T = 3;
 
 // Stack frames end in a word laid out like a ref.  A geometry tag in bits 29..26 makes it the
 // one-word frame of a BVH node whose first child is being evaluated: the low 30 bits are the
@@ -99,6 +106,7 @@ struct DevScene {  // kernel argument
     const uint2* list;          // (first child, n children)
     const uint32_t* child_refs;
     const RR_CONST_AS uint4* prog;  // scene program, 2 uint4 (one 32-byte op) per entry, terminated by OP_END
+    float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
     const RR_CONST_AS DevConst* k;
 };
 
@@ -418,11 +426,17 @@ struct Trav {
     float tmin, tmax;
     uint32_t cur, node, sp;
     bool hitf;  // a hit was accepted since the innermost open first-child call or medium probe began
+    bool cull;  // subtrees whose box the ray misses may be left out (see BVH_CLASS_CULL_*)
 
     __device__ __forceinline__ void set_ray(f3 o_, f3 d_) {
         o = o_;
         d = d_;
         inv = mk3(1.0f / d_.x, 1.0f / d_.y, 1.0f / d_.z);
+        // The intersectors accept a hit whose t is NaN (every comparison with NaN is false): a sphere when
+        // |d|^2 is 0 or not finite, a rect when its direction component and plane distance are both 0.
+        // Such a hit has nothing to do with geometry, so rays that can produce one are never culled.
+        const float a = len2(d_);
+        cull = d_.x != 0.0f && d_.y != 0.0f && d_.z != 0.0f && a >= 1e-10f && a <= 1e10f;
     }
     __device__ __forceinline__ void begin(uint32_t start, f3 o_, f3 d_, float tmin_, float tmax_, uint32_t cur_) {
         set_ray(o_, d_);
@@ -446,55 +460,91 @@ struct Trav {
 template <bool COUNT, class World, class Draw>
 __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk,
                                           uint32_t stride, Counts& cnt) {
-    // ------------------------------------------------ evaluate the node
-    if (m.node != NONE) {
+    // A step has three phases, each taken by every lane whose state asks for it: a BVH node, then
+    // whatever else the lane is at (possibly the child the node phase has just chosen), then the
+    // returns.  A ray alternating between nodes and leaves advances through two records per step
+    // and the wave executes neither phase for the sake of a few lanes only.
+    // ------------------------------------------------ BVH node
+    if (m.node != NONE && dtag(m.node) == RR_TAG_BVH) {
+        const uint32_t idx = didx(m.node);
+        const float4 q0 = sc.bvh[2 * idx], q1 = sc.bvh[2 * idx + 1];
+        m.node = NONE;
+        const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
+        const uint32_t cls = COUNT ? (dextra(right) != BVH_CLASS_NO_BOX ? BVH_CLASS_REFERENCE : BVH_CLASS_NO_BOX) : dextra(right);
+        bool pass = true;
+        if (cls != BVH_CLASS_NO_BOX) {
+            if (COUNT) cnt.box_tests++;
+            // Slab parameters of the three axes, entry and exit ordered by the sign of 1/direction.
+            const float tx0 = (q0.x - m.o.x) * m.inv.x, tx1 = (q1.x - m.o.x) * m.inv.x;
+            const float ty0 = (q0.y - m.o.y) * m.inv.y, ty1 = (q1.y - m.o.y) * m.inv.y;
+            const float tz0 = (q0.z - m.o.z) * m.inv.z, tz1 = (q1.z - m.o.z) * m.inv.z;
+            const bool nx = m.inv.x < 0.0f, ny = m.inv.y < 0.0f, nz = m.inv.z < 0.0f;
+            const float ex = nx ? tx1 : tx0, fx = nx ? tx0 : tx1;
+            const float ey = ny ? ty1 : ty0, fy = ny ? ty0 : ty1;
+            const float ez = nz ? tz1 : tz0, fz = nz ? tz0 : tz1;
+            // aabb.rs:37-52: only axes with a negative 1/direction clip [t_min, t_max], by
+            // `t1 > t_min ? t1 : t_min` and `t0 < t_max ? t0 : t_max` (a NaN never replaces a bound:
+            // fmaxf/fminf keep the other operand too), and the node is rejected once t_max <= t_min.
+            // Bounds only tighten, so testing once after the third axis rejects the same rays.
+            const float lo = fmaxf(fmaxf(m.tmin, nx ? ex : m.tmin), fmaxf(ny ? ey : m.tmin, nz ? ez : m.tmin));
+            const float hi = fminf(fminf(m.tmax, nx ? fx : m.tmax), fminf(ny ? fy : m.tmax, nz ? fz : m.tmax));
+            // (A bound that is NaN on entry — the t of a degenerate hit — stays NaN in the reference and
+            // fails no comparison, where fmaxf/fminf would drop it.)
+            pass = !(hi <= lo) || __builtin_isunordered(m.tmin, m.tmax);
+            if (cls >= BVH_CLASS_CULL_RANGE && m.cull) {
+                // All three slabs of the box grown by the margin, against the segment no accepted hit can lie
+                // outside of.  The margin grows with the squared distance from the ray origin to the farthest
+                // point of the box, as the rounding errors of the intersectors below do.
+                const float ax = fmaxf(fabsf(q0.x - m.o.x), fabsf(q1.x - m.o.x)), ay = fmaxf(fabsf(q0.y - m.o.y), fabsf(q1.y - m.o.y)),
+                            az = fmaxf(fabsf(q0.z - m.o.z), fabsf(q1.z - m.o.z));
+                const float g = sc.cull_eps + sc.cull_k * (ax * ax + ay * ay + az * az);
+                const float gx = g * fabsf(m.inv.x), gy = g * fabsf(m.inv.y), gz = g * fabsf(m.inv.z);
+                const float seg0 = cls == BVH_CLASS_CULL_ANY_T ? 0.0f : m.tmin, seg1 = cls == BVH_CLASS_CULL_ANY_T ? kF32Max : m.tmax;
+                const float enter = fmaxf(fmaxf(seg0, ex - gx), fmaxf(ey - gy, ez - gz));
+                const float leave = fminf(fminf(seg1, fx + gx), fminf(fy + gy, fz + gz));
+                pass = pass && !(leave < enter);
+            }
+        }
+        if (pass) {
+            const uint32_t l = left & REF_MASK, r = right & REF_MASK;
+            const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
+            // In the culling classes evaluating the same child twice over the same or a smaller
+            // range cannot change the outcome.  The counting build evaluates everything.
+            const bool pure = cls >= BVH_CLASS_CULL_RANGE;
+            if (pure && l == r) {
+                m.node = l;  // span-1 node: the second visit repeats the first
+            } else {
+                uint32_t fw;
+                if (!dirpos)
+                    fw = l;  // right first; left follows after a hit and after a miss alike
+                else if (pure)
+                    fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
+                else
+                    fw = frame_word(FK_BVH2, idx);
+                stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
+                m.sp += 1;
+                m.hitf = false;
+                m.node = dirpos ? l : r;
+            }
+        }
+    }
+    // ------------------------------------------------ primitive, list, instance or medium
+    if (m.node != NONE && dtag(m.node) != RR_TAG_BVH) {
         const uint32_t node = m.node;
         const uint32_t tag = dtag(node), idx = didx(node);
         // One address, three 16-byte loads and one wait for whatever kind of record each lane
         // is at (every record array is padded by two words, so reading past a short record
-        // is harmless): lanes at BVH nodes and lanes at primitives wait together instead of
-        // one after the other.
-        const float4* rp = sc.bvh;
-        uint32_t roff = 2 * idx;
-        if (tag == RR_TAG_TRIANGLE) rp = sc.tri, roff = 3 * idx;
+        // is harmless).
+        const float4* rp = sc.tri;
+        uint32_t roff = 3 * idx;
         if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
-        if (tag == RR_TAG_RECT) rp = sc.rect;
-        if (tag == RR_TAG_CUBOID) rp = sc.cuboid;
-        if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere, roff = 3 * idx;
+        if (tag == RR_TAG_RECT) rp = sc.rect, roff = 2 * idx;
+        if (tag == RR_TAG_CUBOID) rp = sc.cuboid, roff = 2 * idx;
+        if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere;
         if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
         const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
         m.node = NONE;
-        if (tag == RR_TAG_BVH) {
-            const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
-            bool pass = true;
-            if (right & BVH_HAS_BOX) {
-                if (COUNT) cnt.box_tests++;
-                pass = test_box_inv(q0, q1, m.o, m.inv, m.tmin, m.tmax);
-            }
-            if (pass) {
-                const uint32_t l = left & REF_MASK, r = right & REF_MASK;
-                const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
-                // Below a node without a constant medium every intersect call is a pure function
-                // of (ray, t range): evaluating the same child twice over the same or a smaller
-                // range cannot change the outcome.  The counting build evaluates everything.
-                const bool pure = !COUNT && !(right & BVH_IMPURE);
-                if (pure && l == r) {
-                    m.node = l;  // span-1 node: the second visit repeats the first
-                } else {
-                    uint32_t fw;
-                    if (!dirpos)
-                        fw = l;  // right first; left follows after a hit and after a miss alike
-                    else if (pure)
-                        fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
-                    else
-                        fw = frame_word(FK_BVH2, idx);
-                    stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
-                    m.sp += 1;
-                    m.hitf = false;
-                    m.node = dirpos ? l : r;
-                }
-            }
-        } else if (tag == RR_TAG_SPHERE) {
+        if (tag == RR_TAG_SPHERE) {
             if (COUNT) cnt.sphere_tests++;
             float t;
             if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, m.o, m.d, m.tmin, m.tmax, t)) {

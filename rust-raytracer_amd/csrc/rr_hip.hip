@@ -282,13 +282,39 @@ struct rr_context {
 namespace {
 
 // ------------------------------------------------------- scene validation
+// What lies below a ref: the true bounds of every primitive (in the space the ref is evaluated
+// in, over the camera's shutter interval) and what kinds of things there are.
+struct Below {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool bounded = true;   // false: something below has no finite bounds
+    bool has_tri = false;  // triangles accept hits outside the caller's t range (collider.rs:627)
+    bool has_medium = false;
+    void add_point(double x, double y, double z) {
+        const double p[3] = {x, y, z};
+        for (int a = 0; a < 3; ++a) {
+            if (!(p[a] == p[a]) || p[a] > 1e30 || p[a] < -1e30) bounded = false;
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void merge(const Below& o) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], o.lo[a]);
+            hi[a] = std::max(hi[a], o.hi[a]);
+        }
+        bounded &= o.bounded;
+        has_tri |= o.has_tri;
+        has_medium |= o.has_medium;
+    }
+    bool empty() const { return lo[0] > hi[0]; }
+};
+
 struct Walker {
     const rr_flat_scene& s;
     std::vector<uint8_t> seen[RR_TAG_COUNT];
     std::vector<uint32_t> owner_sphere, owner_msphere, owner_rect, owner_tri, owner_medium;
     std::vector<uint32_t> inst_depth, inst_chain;
-    std::vector<uint8_t> bvh_impure;  // a constant medium lies below this node
-    uint32_t media_walked = 0;
+    std::vector<Below> bvh_below;  // per BVH node: what its two children hold
     uint32_t max_inst_depth = 0;
     std::string err;
     int err_code = RR_E_INVALID;
@@ -304,7 +330,7 @@ struct Walker {
         owner_medium.assign(s.n_media, NONE);
         inst_depth.assign(s.n_instances, 0);
         inst_chain.assign(static_cast<size_t>(s.n_instances) * MAX_CHAIN, NONE);
-        bvh_impure.assign(s.n_bvh_nodes, 0);
+        bvh_below.assign(s.n_bvh_nodes, Below{});
     }
 
     bool bad(const std::string& m, int code = RR_E_INVALID) {
@@ -317,44 +343,78 @@ struct Walker {
 
     bool mat_ok(uint32_t m) { return m < s.n_materials || bad("primitive references a material outside the table"); }
 
-    // Returns the stack words evaluating `ref` can need, or fails.  `owner` is the
-    // innermost enclosing instance; depth bounds recursion (and rejects cycles together
-    // with the visited marks).
-    bool walk(uint32_t ref, uint32_t owner, uint32_t level, uint32_t& words) {
+    // Returns the stack words evaluating `ref` can need and what lies below it, or fails.
+    // `owner` is the innermost enclosing instance; depth bounds recursion (and rejects cycles
+    // together with the visited marks).
+    bool walk(uint32_t ref, uint32_t owner, uint32_t level, uint32_t& words, Below& below) {
         if (level > 128) return bad("scene tree deeper than 128 levels (or cyclic)", RR_E_LIMIT);
         const uint32_t tag = RR_REF_TAG(ref), idx = RR_REF_INDEX(ref);
         if (tag >= RR_TAG_COUNT || idx >= seen[tag].size()) return bad("geometry ref out of range");
         if (seen[tag][idx]++) return bad("a record is reachable twice: the flattened scene must be a tree (only a BVH node may name one child on both sides)");
         words = 0;
+        below = Below{};
         switch (tag) {
-            case RR_TAG_SPHERE:
+            case RR_TAG_SPHERE: {
                 owner_sphere[idx] = owner;
-                return mat_ok(s.spheres[idx].material);
-            case RR_TAG_MOVING_SPHERE:
+                const rr_sphere& p = s.spheres[idx];
+                const double r = std::fabs(static_cast<double>(p.radius));
+                below.add_point(p.center[0] - r, p.center[1] - r, p.center[2] - r);
+                below.add_point(p.center[0] + r, p.center[1] + r, p.center[2] + r);
+                return mat_ok(p.material);
+            }
+            case RR_TAG_MOVING_SPHERE: {
                 owner_msphere[idx] = owner;
-                return mat_ok(s.moving_spheres[idx].material);
-            case RR_TAG_RECT:
+                const rr_moving_sphere& p = s.moving_spheres[idx];
+                const double r = std::fabs(static_cast<double>(p.radius));
+                // the centre moves linearly in the ray's time (collider.rs:269-271), which the camera draws
+                // from its shutter interval (camera.rs:83): the extreme positions are at the interval's ends
+                for (const float t : {s.camera.shutter_open, s.camera.shutter_close}) {
+                    const double f = (static_cast<double>(t) - p.time0) / (static_cast<double>(p.time1) - p.time0);
+                    double c[3];
+                    for (int a = 0; a < 3; ++a) c[a] = p.center0[a] + f * (static_cast<double>(p.center1[a]) - p.center0[a]);
+                    below.add_point(c[0] - r, c[1] - r, c[2] - r);
+                    below.add_point(c[0] + r, c[1] + r, c[2] + r);
+                }
+                return mat_ok(p.material);
+            }
+            case RR_TAG_RECT: {
                 owner_rect[idx] = owner;
-                if (s.rects[idx].axis > RR_RECT_YZ) return bad("rect axis out of range");
-                return mat_ok(s.rects[idx].material);
-            case RR_TAG_TRIANGLE:
+                const rr_rect& p = s.rects[idx];
+                if (p.axis > RR_RECT_YZ) return bad("rect axis out of range");
+                for (const float a : {p.a0, p.a1})
+                    for (const float b : {p.b0, p.b1}) {
+                        if (p.axis == RR_RECT_XY) below.add_point(a, b, p.k);
+                        else if (p.axis == RR_RECT_XZ) below.add_point(a, p.k, b);
+                        else below.add_point(p.k, a, b);
+                    }
+                return mat_ok(p.material);
+            }
+            case RR_TAG_TRIANGLE: {
                 owner_tri[idx] = owner;
-                return mat_ok(s.triangles[idx].material);
+                const rr_triangle& p = s.triangles[idx];
+                below.add_point(p.p0[0], p.p0[1], p.p0[2]);
+                below.add_point(p.p1[0], p.p1[1], p.p1[2]);
+                below.add_point(p.p2[0], p.p2[1], p.p2[2]);
+                below.has_tri = true;
+                return mat_ok(p.material);
+            }
             case RR_TAG_CUBOID: {
                 const uint32_t first = s.cuboids[idx].first_rect;
                 if (first > s.n_rects || s.n_rects - first < 6) return bad("cuboid rect range out of bounds");
                 for (uint32_t i = 0; i < 6; ++i) {
                     uint32_t w;
-                    if (!walk(RR_REF(RR_TAG_RECT, first + i), owner, level + 1, w)) return false;
+                    Below side;
+                    if (!walk(RR_REF(RR_TAG_RECT, first + i), owner, level + 1, w, side)) return false;
+                    below.merge(side);
                 }
                 return true;
             }
             case RR_TAG_MEDIUM: {
                 owner_medium[idx] = owner;
-                ++media_walked;
                 if (!mat_ok(s.media[idx].material)) return false;
                 uint32_t w;
-                if (!walk(s.media[idx].boundary, owner, level + 1, w)) return false;
+                if (!walk(s.media[idx].boundary, owner, level + 1, w, below)) return false;
+                below.has_medium = true;
                 words = FRAME_WORDS_MEDIUM + w;
                 return true;
             }
@@ -368,22 +428,42 @@ struct Walker {
                 inst_chain[idx * MAX_CHAIN + depth - 1] = idx;
                 max_inst_depth = std::max(max_inst_depth, depth);
                 uint32_t w;
-                if (!walk(in.child, idx, level + 1, w)) return false;
+                Below inner;
+                if (!walk(in.child, idx, level + 1, w, inner)) return false;
                 words = FRAME_WORDS_INST + w;
+                // bounds of the child's box seen from outside the instance (collider.rs:484, 513-517)
+                below = inner;
+                if (!inner.empty()) {
+                    for (int a = 0; a < 3; ++a) below.lo[a] = 1e300, below.hi[a] = -1e300;
+                    for (int c = 0; c < 8; ++c) {
+                        double q[3] = {(c & 1) ? inner.hi[0] : inner.lo[0], (c & 2) ? inner.hi[1] : inner.lo[1], (c & 4) ? inner.hi[2] : inner.lo[2]};
+                        if (in.kind == RR_INST_TRANSLATE) {
+                            for (int a = 0; a < 3; ++a) q[a] += in.v[a];
+                        } else {
+                            const double sn = in.v[0], cs = in.v[1];
+                            const int i0 = in.kind == RR_INST_ROTATE_X ? 1 : 0, i1 = in.kind == RR_INST_ROTATE_Z ? 1 : 2;
+                            const double u = cs * q[i0] + sn * q[i1], v = -sn * q[i0] + cs * q[i1];
+                            q[i0] = u, q[i1] = v;
+                        }
+                        below.add_point(q[0], q[1], q[2]);
+                    }
+                }
                 return true;
             }
             case RR_TAG_BVH: {
                 const rr_bvh_node& n = s.bvh_nodes[idx];
                 if (n.axis > 2) return bad("BVH node axis out of range");
                 uint32_t wl = 0, wr = 0;
-                const uint32_t media_before = media_walked;
-                if (!walk(n.left, owner, level + 1, wl)) return false;
+                Below bl, br;
+                if (!walk(n.left, owner, level + 1, wl, bl)) return false;
                 if (n.right != n.left) {
-                    if (!walk(n.right, owner, level + 1, wr)) return false;
+                    if (!walk(n.right, owner, level + 1, wr, br)) return false;
                 } else {
                     wr = wl;
                 }
-                bvh_impure[idx] = media_walked != media_before;
+                below = bl;
+                below.merge(br);
+                bvh_below[idx] = below;
                 words = FRAME_WORDS_BVH + std::max(wl, wr);
                 return true;
             }
@@ -394,7 +474,9 @@ struct Walker {
                 uint32_t wmax = 0;
                 for (uint32_t i = 0; i < l.n_children; ++i) {
                     uint32_t w;
-                    if (!walk(s.child_refs[l.first_child + i], owner, level + 1, w)) return false;
+                    Below c;
+                    if (!walk(s.child_refs[l.first_child + i], owner, level + 1, w, c)) return false;
+                    below.merge(c);
                     wmax = std::max(wmax, w);
                 }
                 words = FRAME_WORDS_LIST + wmax;
@@ -723,23 +805,57 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     }
     Walker wk(*s);
     uint32_t stack_words = 0;
-    if (!wk.walk(s->root, NONE, 0, stack_words)) return fail(wk.err_code, "rr_scene_upload: " + wk.err);
+    Below everything;
+    if (!wk.walk(s->root, NONE, 0, stack_words, everything)) return fail(wk.err_code, "rr_scene_upload: " + wk.err);
     stack_words = std::max(stack_words, 1u);
     const size_t lds_bytes = static_cast<size_t>(stack_words) * 256u * 4u;
     if (lds_bytes > static_cast<size_t>(ctx->max_dynamic_lds))
         return fail(RR_E_LIMIT, "rr_scene_upload: traversal stack of " + std::to_string(stack_words) +
                                     " words per lane exceeds the LDS available to one workgroup");
 
+    // Margin of the culling test.  The reference's intersectors accept hits by rounded arithmetic, so a ray
+    // can be accepted by a primitive it misses geometrically, by a distance that must stay inside the margin:
+    //   rects, triangles: the hit point and the edge tests are off by some ulps of the coordinates involved,
+    //     below 1e-6 * (|coordinates| + distance from the ray origin);
+    //   spheres: the discriminant half_b^2 - a*c (collider.rs:282) carries an absolute error of about
+    //     21 * 2^-24 * |d|^2 * |oc|^2, which accepts rays passing up to 0.65e-6 * |oc|^2 / r outside a sphere
+    //     of radius r seen from distance |oc| >= r.
+    // The kernels grow a node's box by cull_eps + cull_k * (largest squared distance from the ray origin to
+    // the box): cull_eps = 2e-5 * (largest coordinate below any BVH node), an order of magnitude above the
+    // first bound inside the scene; cull_k = max(4e-6 / smallest radius, 1e-6 / that coordinate), six times
+    // the second bound and enough for the first at any distance.
+    double extent = 1.0;
+    for (const Below& b : wk.bvh_below)
+        if (b.bounded && !b.empty())
+            for (int a = 0; a < 3; ++a) extent = std::max({extent, std::fabs(b.lo[a]), std::fabs(b.hi[a])});
+    double r_min = 1e300;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) r_min = std::min(r_min, std::fabs(static_cast<double>(s->spheres[i].radius)));
+    for (uint32_t i = 0; i < s->n_moving_spheres; ++i) r_min = std::min(r_min, std::fabs(static_cast<double>(s->moving_spheres[i].radius)));
+    const double cull_eps = 2e-5 * extent;
+    const double cull_k = std::max(r_min > 0.0 ? 4e-6 / r_min : 1e300, 1e-6 / extent);
+
     // ---- pack
     // The traversal machine reads three 16-byte words at every record it visits, whatever the
-    // record's length: the arrays it reads that way end in two words of padding and are never empty.
-    constexpr size_t PAD = 2;
+    // record's length: the arrays it reads that way end in three words of padding and are never empty.
+    constexpr size_t PAD = 3;
     std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2 + PAD);
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
         const rr_bvh_node& n = s->bvh_nodes[i];
         bvh[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], u2f(to_dref(n.left, n.axis)));
-        bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2],
-                                     u2f(to_dref(n.right) | (n.has_box ? BVH_HAS_BOX : 0u) | (wk.bvh_impure[i] ? BVH_IMPURE : 0u)));
+        // How the production kernels may treat the node (the counting kernels treat every node as the
+        // reference does).  If no constant medium lies below and the stored box holds everything below
+        // (within half the margin the kernels add), a ray that misses the box cannot be accepted by
+        // anything below: the subtree need not be entered, and no visit of it needs repeating.
+        const Below& b = wk.bvh_below[i];
+        uint32_t cls = BVH_CLASS_NO_BOX;
+        if (n.has_box) {
+            cls = BVH_CLASS_REFERENCE;
+            bool holds = !b.has_medium && b.bounded && !b.empty();
+            for (int a = 0; a < 3 && holds; ++a)
+                holds = static_cast<double>(n.bmin[a]) - 0.5 * cull_eps <= b.lo[a] && b.hi[a] <= static_cast<double>(n.bmax[a]) + 0.5 * cull_eps;
+            if (holds) cls = b.has_tri ? BVH_CLASS_CULL_ANY_T : BVH_CLASS_CULL_RANGE;
+        }
+        bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, cls)));
     }
     std::vector<float4> sphere(s->n_spheres + PAD);
     std::vector<uint2> sphere_meta(s->n_spheres);
@@ -897,6 +1013,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->has_subtrees = false;
     for (const Op& op : pb.ops) ctx->has_subtrees |= (op.code & 0xFFu) == OP_SUBTREE;
     ctx->root = to_dref(s->root);
+    ctx->sc.cull_eps = static_cast<float>(cull_eps);
+    ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
     ctx->info.wavefront = ctx->has_subtrees ? 1u : 0u;
     ctx->has_scene = true;
     return RR_OK;

@@ -17,15 +17,18 @@ def compare_hits(got, gold, exact_t=True):
     hit = gold["prim_id"] >= 0
     assert np.array_equal(got["front_face"][hit], gold["front_face"][hit])
     if exact_t:
-        assert np.array_equal(got["t"][hit], gold["t"][hit])
-        assert np.array_equal(got["point"][hit], gold["point"][hit])
+        # equal_nan: a degenerate ray (zero direction) is "hit" at t = NaN by the reference's comparisons
+        assert np.array_equal(got["t"][hit], gold["t"][hit], equal_nan=True)
+        assert np.array_equal(got["point"][hit], gold["point"][hit], equal_nan=True)
     else:
-        assert np.allclose(got["t"][hit], gold["t"][hit], rtol=1e-5, atol=0)
-        dp = np.linalg.norm(got["point"][hit] - gold["point"][hit], axis=1)
-        assert (dp <= 1e-5 * np.maximum(np.linalg.norm(gold["point"][hit], axis=1), 1.0)).all(), dp.max()
-    assert np.allclose(got["normal"][hit], gold["normal"][hit], rtol=1e-5, atol=1e-7)
+        assert np.allclose(got["t"][hit], gold["t"][hit], rtol=1e-5, atol=0, equal_nan=True)
+        ok = np.isfinite(gold["point"][hit]).all(axis=1)
+        dp = np.linalg.norm(got["point"][hit][ok] - gold["point"][hit][ok], axis=1)
+        assert (dp <= 1e-5 * np.maximum(np.linalg.norm(gold["point"][hit][ok], axis=1), 1.0)).all(), dp.max()
+    assert np.allclose(got["normal"][hit], gold["normal"][hit], rtol=1e-5, atol=1e-7, equal_nan=True)
     # u, v of spheres go through acos / atan2: last-bit differences between math libraries
-    assert np.allclose(got["u"][hit], gold["u"][hit], atol=1e-6) and np.allclose(got["v"][hit], gold["v"][hit], atol=1e-6)
+    assert np.allclose(got["u"][hit], gold["u"][hit], atol=1e-6, equal_nan=True)
+    assert np.allclose(got["v"][hit], gold["v"][hit], atol=1e-6, equal_nan=True)
 
 
 @pytest.mark.parametrize("name", sorted(G.SCENES))

@@ -65,6 +65,40 @@ def test_primary_hits_honour_the_t_range(gpu_ctx):
     assert len(gpu_ctx.primary_hits(np.zeros((0, 7), dtype=np.float32))) == 0
 
 
+def _stress_rays(flat, n, seed):
+    """Rays from inside and around the scene in every direction, with the special cases a slab test trips over:
+    axis-parallel directions (zero and negative-zero components), origins on box planes, long and short directions."""
+    rng = np.random.default_rng(seed)
+    look = np.array(flat.camera.origin[:], dtype=np.float32)
+    span = max(300.0, float(np.abs(look).max()))
+    o = (rng.uniform(-1, 1, (n, 3)) * span * 0.6).astype(np.float32)
+    o[: n // 4] = look  # a quarter leave the camera position
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d *= np.float32(10.0) ** rng.uniform(-2, 2.5, (n, 1)).astype(np.float32)  # directions are never normalised (render.rs:32)
+    k = n // 8
+    d[:k, rng.integers(0, 3)] = 0.0
+    d[k:2 * k, 0] = -0.0
+    d[2 * k:3 * k, 1:] = 0.0
+    d[3 * k:4 * k] = np.round(d[3 * k:4 * k])  # many exact zeros and ties
+    o[4 * k:5 * k] = np.round(o[4 * k:5 * k] / 5) * 5  # origins on lattice planes, where many boxes and rects lie
+    t = rng.uniform(0, 1, (n, 1)).astype(np.float32)
+    return np.concatenate([o, d, t], axis=1)
+
+
+@pytest.mark.parametrize("name,kw", [("suzanne", {}), ("spheres", {}), ("final", {}),
+                                     ("mesh", dict(n_triangles=20000, n_spheres=2000))])
+def test_culling_and_visit_skipping_never_change_a_hit(gpu_ctx, name, kw):
+    """The production traversal skips subtrees whose (margin-grown) box the ray misses and visits it need not repeat;
+    the oracle makes every visit the reference makes.  200 000 adversarial rays per scene: identical records."""
+    b, flat, _ = host.build_config_scene(name, seed=3, **kw)
+    gpu_ctx.upload(flat)
+    rays = _stress_rays(flat, 200_000, seed=9)
+    got = gpu_ctx.primary_hits(rays, seed=4)
+    want = O.primary_hits(flat, rays, seed=4)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+    compare_hits(got, want, exact_t=(name != "final"))
+
+
 # ------------------------------------------------------------ whole renders
 def render_both(ctx, flat, p, n_threads=16):
     ctx.upload(flat)
