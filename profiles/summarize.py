@@ -26,11 +26,19 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    for k in ("k_render<false>", "k_render<true>", "k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_shade", "k_wf_init",
+    if "k_render<false" in name:
+        return "k_render<false>"
+    if "k_render<true" in name:
+        return "k_render<true>"
+    for k in ("k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_shade", "k_wf_init",
               "k_wf_accumulate", "k_resolve", "k_cast_u8"):
         if k in name:
             return k
     return None
+
+
+def counting(name):
+    return "k_render<true" in name or "k_wf_traverse<true>" in name
 
 
 def last_json_line(path):
@@ -52,7 +60,7 @@ trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if trace:
     rows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
     rows = [r for r in rows if short(r["Kernel_Name"])]
-    cut = next((i for i, r in enumerate(rows) if "<true>" in r["Kernel_Name"]), len(rows))
+    cut = next((i for i, r in enumerate(rows) if counting(r["Kernel_Name"])), len(rows))
     rows = rows[:cut]
     steps = bench["steps"] + bench["warmup"]
     casts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_cast_u8"]
@@ -85,7 +93,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if pmc_bench is None:
         pmc_bench = last_json_line(d + ".json")
     rows = [r for r in csv.DictReader(open(files[0])) if short(r["Kernel_Name"])]
-    ids = [int(r["Dispatch_Id"]) for r in rows if "<true>" in r["Kernel_Name"]]
+    ids = [int(r["Dispatch_Id"]) for r in rows if counting(r["Kernel_Name"])]
     cut = min(ids) if ids else 1 << 62
     for r in rows:
         if int(r["Dispatch_Id"]) >= cut:
@@ -135,7 +143,7 @@ if pmc_bench:
         for f in files:
             acc = collections.defaultdict(list)
             rows = [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"])]
-            ids = [int(r["Dispatch_Id"]) for r in rows if "<true>" in r["Kernel_Name"]]
+            ids = [int(r["Dispatch_Id"]) for r in rows if counting(r["Kernel_Name"])]
             cut = min(ids) if ids else 1 << 62
             for r in rows:
                 if r["Counter_Name"] in ("MeanOccupancyPerCU", "VALUUtilization", "VALUBusy") and int(r["Dispatch_Id"]) < cut:

@@ -814,7 +814,9 @@ struct Op {
 // SceneColliders::intersect (collider.rs:751-772) for the world ray (wo, wd).  (tmax, cur) carry
 // the closest hit so far through the fold; `live` is false only for lanes whose first medium
 // probe missed, until that medium's end op.
-template <bool COUNT>
+// VEC = false builds an interpreter for programs without OP_LEAF_REF and OP_SUBTREE (scenes made of rects,
+// spheres, cuboids, instances and media of those): no vector memory access, no traversal machine.
+template <bool COUNT, bool VEC = true>
 __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, bool enabled,
                                          Rng& rng, uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
     // `enabled` is false for lanes that only ride along (the caller keeps this call in wave-uniform
@@ -876,9 +878,9 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
                 tmax = t;
                 cur = op.ref;
             }
-        } else if (code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
+        } else if (VEC && code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
             if (live) eval_leaf<COUNT>(sc, uni(op.ref), o, d, time, tmin, tmax, cur, cnt);
-        } else if (code == OP_SUBTREE) {  // BVH (or any shape the program does not flatten): per-lane machine
+        } else if (VEC && code == OP_SUBTREE) {  // BVH (or any shape the program does not flatten): per-lane machine
             if (live) machine<COUNT>(sc, uni(op.ref), wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
         } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
             if (COUNT && live) cnt.inst_visits++;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool VEC>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
                                                 unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
         t = ro.x + rd.y;
         ref = NONE;
 #else
-        traverse<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+        traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
 #endif
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
@@ -273,6 +273,7 @@ struct rr_context {
     // and a grow-only workspace (path state, two queues, queue controls) with a pinned word the
     // host polls the live-path count through
     bool has_subtrees = false;
+    bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
     uint32_t root = NONE;
     void* wf_mem = nullptr;
     size_t wf_bytes = 0;
@@ -1011,7 +1012,11 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
     ctx->has_subtrees = false;
-    for (const Op& op : pb.ops) ctx->has_subtrees |= (op.code & 0xFFu) == OP_SUBTREE;
+    ctx->prog_vector_ops = false;
+    for (const Op& op : pb.ops) {
+        ctx->has_subtrees |= (op.code & 0xFFu) == OP_SUBTREE;
+        ctx->prog_vector_ops |= (op.code & 0xFFu) == OP_SUBTREE || (op.code & 0xFFu) == OP_LEAF_REF;
+    }
     ctx->root = to_dref(s->root);
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
@@ -1129,7 +1134,10 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
         ctx->timed = true;
         return resolve_slices(ctx, p, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
     }
-    const void* kernel = count ? reinterpret_cast<const void*>(&k_render<true>) : reinterpret_cast<const void*>(&k_render<false>);
+    using RenderKernel = void (*)(DevScene, RenderArgs, float*, unsigned long long*);
+    const RenderKernel render_kernel = ctx->prog_vector_ops ? (count ? k_render<true, true> : k_render<false, true>)
+                                                            : (count ? k_render<true, false> : k_render<false, false>);
+    const void* kernel = reinterpret_cast<const void*>(render_kernel);
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     int grid = 0;
     if (int rc = launch_dims(ctx, lds, kernel, &grid)) return rc;
@@ -1154,12 +1162,8 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
         a.slice_out = s0;
         const uint64_t blocks_needed = (a.n_items + 255u) / 256u;
         const uint32_t g = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(grid), std::max<uint64_t>(blocks_needed, 1)));
-        if (count)
-            hipLaunchKernelGGL(k_render<true>, dim3(g), dim3(256), lds, stream, ctx->sc, a, static_cast<float*>(d_slice_sums),
-                               static_cast<unsigned long long*>(d_counters));
-        else
-            hipLaunchKernelGGL(k_render<false>, dim3(g), dim3(256), lds, stream, ctx->sc, a, static_cast<float*>(d_slice_sums),
-                               static_cast<unsigned long long*>(d_counters));
+        hipLaunchKernelGGL(render_kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, static_cast<float*>(d_slice_sums),
+                           static_cast<unsigned long long*>(d_counters));
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev1, stream));

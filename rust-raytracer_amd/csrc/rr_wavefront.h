@@ -63,7 +63,6 @@ __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_
 __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState st, uint32_t* __restrict__ queue, WfCtl* ctl,
                                                  unsigned long long* counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
     if (p < a.n_paths) {
         uint32_t pixel, sample;
         wf_path_key(a, p, pixel, sample);
@@ -77,15 +76,14 @@ __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState 
         st.ray_d[p] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(a.max_depth));
         st.thr[p] = make_float4(1.f, 1.f, 1.f, 0.f);
         queue[p] = p;
-        cnt.samples++;
     }
     if (p == 0) {
         ctl[0].count = a.n_paths;
         ctl[0].cursor = 0;
         ctl[1].count = ctl[1].cursor = 0;
         ctl[2].count = ctl[2].cursor = 0;
+        if (counters) atomicAdd(&counters[0], static_cast<unsigned long long>(a.n_paths));  // samples started: one per path
     }
-    flush_counts(cnt, counters);
 }
 
 // pixel_color of render.rs:93-100 for one slot: the batch's sample values added in sample order.
