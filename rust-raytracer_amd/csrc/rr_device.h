@@ -54,8 +54,9 @@ constexpr uint32_t FRAME_WORDS_LIST = 2, FRAME_WORDS_BVH = 1, FRAME_WORDS_INST =
 
 struct DevMaterial {  // 32 B
     uint32_t type, texture;
-    float r, g, b, param;
-    uint32_t pad0, pad1;
+    float r, g, b, param;  // (r, g, b): the material's own colour, or its texture's when that is one solid colour
+    uint32_t solid;        // 1: (r, g, b) is what Texture::get_color would return everywhere (texture.rs:67)
+    uint32_t pad1;
 };
 struct DevTexture {  // 48 B
     uint32_t type, index, depth, pad;
@@ -79,8 +80,8 @@ struct DevImage {
 // What only shading and ray generation read (once per bounce or per sample): kept in device
 // memory behind one pointer so that its ~60 dwords do not occupy SGPRs during traversal.
 struct DevConst {
-    const uint2* sphere_meta;     // (material, owner instance)
-    const uint2* tri_meta;        // (material, owner instance)
+    const uint2* sphere_meta;     // (material, owner word)
+    const uint2* tri_meta;        // (material, owner word)
     const DevMaterial* materials;
     const DevTexture* textures;
     const float* perlin_vec;      // 256*3 per table
@@ -96,13 +97,13 @@ struct DevConst {
 struct DevScene {  // kernel argument
     const float4* bvh;          // 2 per node: (min.xyz, left), (max.xyz, right)
     const float4* sphere;       // (center.xyz, radius)
-    const float4* msphere;      // 3 per record: (c0.xyz, time0), (c1.xyz, time1), (radius, material, owner, -)
-    const float4* rect;         // 2 per record: (a0, a1, b0, b1), (k, axis, material, owner)
+    const float4* msphere;      // 3 per record: (c0.xyz, time0), (c1.xyz, time1), (radius, material, owner word, -)
+    const float4* rect;         // 2 per record: (a0, a1, b0, b1), (k, axis, material, owner word)
     const float4* tri;          // 3 per record: p0.xyz p1.x | p1.yz p2.xy | p2.z n.xyz
     const float4* cuboid;       // 2 per record: (p0.xyz, first rect), (p1.xyz, 1 if the six rects are the constructor's)
-    const uint4* medium;        // (boundary, neg_inv_density bits, material, owner instance)
-    const float4* inst;         // 2 per record: (kind, child, v0, v1), (v2, depth, -, -)
-    const uint32_t* inst_chain; // MAX_CHAIN per instance: enclosing instances, outermost first, itself last
+    const uint4* medium;        // (boundary, neg_inv_density bits, material, owner word)
+    const float4* inst;         // 2 per record: the instance record (see inst_apply_ray), (child, depth, -, -)
+    const float4* chain_rec;    // MAX_CHAIN per instance: the records of its enclosing instances, outermost first, itself last
     const uint2* list;          // (first child, n children)
     const uint32_t* child_refs;
     const RR_CONST_AS uint4* prog;  // scene program, 2 uint4 (one 32-byte op) per entry, terminated by OP_END
@@ -190,15 +191,14 @@ constexpr uint32_t CAMERA_BOUNCE = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------- instances
 // Ray into the space of instance ii (collider.rs:481 translate, 499-509 rotate).
-__device__ __forceinline__ void inst_apply_ray(const DevScene& sc, uint32_t ii, f3& o, f3& d) {
-    const float4 a = sc.inst[2 * ii];
+// An instance record is (kind, v.x, v.y, v.z) for a translation and (kind, sin, cos, -) for a rotation.
+__device__ __forceinline__ void inst_apply_ray(float4 a, f3& o, f3& d) {
     const uint32_t kind = __float_as_uint(a.x);
     if (kind == RR_INST_TRANSLATE) {
-        const float v2 = sc.inst[2 * ii + 1].x;
-        o = o - mk3(a.z, a.w, v2);
+        o = o - mk3(a.y, a.z, a.w);
         return;
     }
-    const float s = a.z, c = a.w;
+    const float s = a.y, c = a.z;
     if (kind == RR_INST_ROTATE_Y) {  // others = (X, Z)
         f3 no = o, nd = d;
         no.x = c * o.x - s * o.z;
@@ -228,24 +228,28 @@ __device__ __forceinline__ void inst_apply_ray(const DevScene& sc, uint32_t ii, 
 __device__ __forceinline__ uint32_t inst_depth(const DevScene& sc, uint32_t ii) {
     return __float_as_uint(sc.inst[2 * ii + 1].y);
 }
-// World ray → ray inside the first `levels` instances of owner's chain.
-__device__ __forceinline__ void localize(const DevScene& sc, uint32_t owner, uint32_t levels, f3 wo, f3 wd, f3& o, f3& d) {
+// "Owner" words name the innermost instance enclosing a primitive together with how many instances
+// enclose it, so that the records of the whole chain can be fetched at once.
+constexpr uint32_t OWNER_DEPTH_SHIFT = 28;
+__host__ __device__ inline uint32_t owner_word(uint32_t inst, uint32_t depth) { return depth == 0 ? 0u : (inst | (depth << OWNER_DEPTH_SHIFT)); }
+__host__ __device__ inline uint32_t owner_depth(uint32_t w) { return w >> OWNER_DEPTH_SHIFT; }
+__host__ __device__ inline uint32_t owner_inst(uint32_t w) { return w & ((1u << OWNER_DEPTH_SHIFT) - 1u); }
+// World ray → ray inside the first `levels` instances of the chain of instance `inst`.
+__device__ __forceinline__ void localize(const DevScene& sc, uint32_t inst, uint32_t levels, f3 wo, f3 wd, f3& o, f3& d) {
     o = wo;
     d = wd;
-    for (uint32_t k = 0; k < levels; ++k) inst_apply_ray(sc, sc.inst_chain[owner * MAX_CHAIN + k], o, d);
+    for (uint32_t k = 0; k < levels; ++k) inst_apply_ray(sc.chain_rec[inst * MAX_CHAIN + k], o, d);
 }
 
 // Hit back out of instance ii; `rd` is the ray direction INSIDE the instance
 // (collider.rs:484-485 translate, 513-523 rotate: set_face_normal against that ray).
-__device__ __forceinline__ void inst_apply_hit(const DevScene& sc, uint32_t ii, f3 rd, f3& p, f3& nrm, bool& front) {
-    const float4 a = sc.inst[2 * ii];
+__device__ __forceinline__ void inst_apply_hit(float4 a, f3 rd, f3& p, f3& nrm, bool& front) {
     const uint32_t kind = __float_as_uint(a.x);
     f3 outn = nrm;
     if (kind == RR_INST_TRANSLATE) {
-        const float v2 = sc.inst[2 * ii + 1].x;
-        p = p + mk3(a.z, a.w, v2);
+        p = p + mk3(a.y, a.z, a.w);
     } else {
-        const float s = a.z, c = a.w;
+        const float s = a.y, c = a.z;
         f3 np = p;
         if (kind == RR_INST_ROTATE_Y) {
             np.x = c * p.x + s * p.z;
@@ -618,9 +622,9 @@ __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const Wor
             stk[m.sp * stride] = frame_word(FK_INST, idx);
             m.sp += 1;
             f3 o = m.o, d = m.d;
-            inst_apply_ray(sc, idx, o, d);
+            inst_apply_ray(sc.inst[2 * idx], o, d);
             m.set_ray(o, d);
-            m.node = __float_as_uint(sc.inst[2 * idx].y);
+            m.node = __float_as_uint(sc.inst[2 * idx + 1].x);
         } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
             if (COUNT) cnt.inst_visits++;
             stk[m.sp * stride] = __float_as_uint(m.tmin);
@@ -959,9 +963,17 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
         h.mat = m.z;
         owner = m.w;
     }
-    const uint32_t depth = owner == NONE ? 0u : inst_depth(sc, owner);
-    f3 o, d;
-    localize(sc, owner, depth, wo, wd, o, d);
+    // the ray in the primitive's space; the directions inside the two outermost instances are kept for the way back
+    const uint32_t depth = owner_depth(owner);
+    const float4* chain = sc.chain_rec + owner_inst(owner) * MAX_CHAIN;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 c0 = depth > 0 ? chain[0] : zero4, c1 = depth > 1 ? chain[1] : zero4;
+    f3 o = wo, d = wd;
+    if (depth > 0) inst_apply_ray(c0, o, d);
+    const f3 d1 = d;
+    if (depth > 1) inst_apply_ray(c1, o, d);
+    const f3 d2 = d;
+    for (uint32_t k = 2; k < depth; ++k) inst_apply_ray(chain[k], o, d);
     h.p = o + d * t;
     if (tag == RR_TAG_SPHERE || tag == RR_TAG_MOVING_SPHERE) {
         f3 center;
@@ -1006,11 +1018,13 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
         h.n = mk3(1.0f, 0.0f, 0.0f);
         h.front = true;
     }
-    for (uint32_t k = depth; k > 0; --k) {
+    for (uint32_t k = depth; k > 2; --k) {
         f3 ko, kd;
-        localize(sc, owner, k, wo, wd, ko, kd);  // the ray inside instance k-1 of the chain
-        inst_apply_hit(sc, sc.inst_chain[owner * MAX_CHAIN + k - 1], kd, h.p, h.n, h.front);
+        localize(sc, owner_inst(owner), k, wo, wd, ko, kd);  // the ray inside instance k-1 of the chain
+        inst_apply_hit(chain[k - 1], kd, h.p, h.n, h.front);
     }
+    if (depth > 1) inst_apply_hit(c1, d2, h.p, h.n, h.front);
+    if (depth > 0) inst_apply_hit(c0, d1, h.p, h.n, h.front);
     return h;
 }
 
@@ -1163,8 +1177,9 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     }
     const DevMaterial m = sc.k->materials[rec.mat];
     f3 attenuation;
+    const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
-        out.terminal = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+        out.terminal = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
         return false;
     }
     // scatter (material.rs:85-169).  ray_color throws the scattered direction away (render.rs:32), so
@@ -1172,11 +1187,11 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     // cosine direction of a Lambertian, a dielectric's reflect-or-refract coin, an isotropic direction —
     // are not taken from the stream at all (the CPU oracle follows the same rule).
     if (m.type == RR_MAT_LAMBERTIAN) {  // material.rs:85-92
-        attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+        attenuation = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
     } else if (m.type == RR_MAT_GLOSSY) {  // material.rs:121-126: the fuzz draw decides whether the path ends
         const f3 reflected = unit3(wd) - rec.n * 2.0f * dot3(unit3(wd), rec.n);
         const f3 sd = reflected + random_in_unit_sphere(g) * m.param;
-        attenuation = mk3(m.r, m.g, m.b);
+        attenuation = own;
         if (!(dot3(sd, rec.n) > 0.0f)) {
             out.terminal = mk3(0.0f, 0.0f, 0.0f);
             return false;
@@ -1184,7 +1199,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: always scatters, attenuation 1
         attenuation = mk3(1.0f, 1.0f, 1.0f);
     } else {  // isotropic, material.rs:150-154
-        attenuation = texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+        attenuation = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
     }
     // render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal
     const f3 w = unit3(rec.n);  // vec3.rs:205-215

@@ -342,6 +342,9 @@ struct Walker {
         return false;
     }
 
+    // owner word of a primitive whose innermost enclosing instance is `inst` (NONE: none)
+    uint32_t owner(uint32_t inst) const { return inst == NONE ? 0u : owner_word(inst, inst_depth[inst]); }
+
     bool mat_ok(uint32_t m) { return m < s.n_materials || bad("primitive references a material outside the table"); }
 
     // Returns the stack words evaluating `ref` can need and what lies below it, or fails.
@@ -686,7 +689,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, float* sums, unsigne
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
         if (a.n_paths != 0) {
             const uint32_t path_blocks = (a.n_paths + 255u) / 256u;
-            hipLaunchKernelGGL(k_wf_init, dim3(path_blocks), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
+            hipLaunchKernelGGL(k_wf_init, dim3(std::min<uint32_t>(path_blocks, static_cast<uint32_t>(ctx->n_cus) * 32u)), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
             HIP_TRY(hipGetLastError());
             uint32_t live = a.n_paths;  // upper bound of the queue length, refreshed at every poll
             // a path ends at the latest in the ray_color call that finds its depth used up (render.rs:16)
@@ -864,7 +867,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const rr_sphere& p = s->spheres[i];
         sphere[i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
-        sphere_meta[i] = make_uint2(p.material, wk.owner_sphere[i]);
+        sphere_meta[i] = make_uint2(p.material, wk.owner(wk.owner_sphere[i]));
         ctx->id_sphere[i] = p.prim_id;
     }
     std::vector<float4> msphere(static_cast<size_t>(s->n_moving_spheres) * 3 + PAD);
@@ -873,7 +876,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         const rr_moving_sphere& p = s->moving_spheres[i];
         msphere[3 * i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.time0);
         msphere[3 * i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time1);
-        msphere[3 * i + 2] = make_float4(p.radius, u2f(p.material), u2f(wk.owner_msphere[i]), 0.f);
+        msphere[3 * i + 2] = make_float4(p.radius, u2f(p.material), u2f(wk.owner(wk.owner_msphere[i])), 0.f);
         ctx->id_msphere[i] = p.prim_id;
     }
     std::vector<float4> rect(static_cast<size_t>(s->n_rects) * 2 + PAD);
@@ -881,7 +884,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     for (uint32_t i = 0; i < s->n_rects; ++i) {
         const rr_rect& p = s->rects[i];
         rect[2 * i] = make_float4(p.a0, p.a1, p.b0, p.b1);
-        rect[2 * i + 1] = make_float4(p.k, u2f(p.axis), u2f(p.material), u2f(wk.owner_rect[i]));
+        rect[2 * i + 1] = make_float4(p.k, u2f(p.axis), u2f(p.material), u2f(wk.owner(wk.owner_rect[i])));
         ctx->id_rect[i] = p.prim_id;
     }
     std::vector<float4> tri(static_cast<size_t>(s->n_triangles) * 3 + PAD);
@@ -892,7 +895,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         tri[3 * i] = make_float4(p.p0[0], p.p0[1], p.p0[2], p.p1[0]);
         tri[3 * i + 1] = make_float4(p.p1[1], p.p1[2], p.p2[0], p.p2[1]);
         tri[3 * i + 2] = make_float4(p.p2[2], p.normal[0], p.normal[1], p.normal[2]);
-        tri_meta[i] = make_uint2(p.material, wk.owner_tri[i]);
+        tri_meta[i] = make_uint2(p.material, wk.owner(wk.owner_tri[i]));
         ctx->id_tri[i] = p.prim_id;
     }
     std::vector<float4> cuboid(static_cast<size_t>(s->n_cuboids) * 2 + PAD);
@@ -918,14 +921,19 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         const rr_medium& p = s->media[i];
         uint32_t nid;
         std::memcpy(&nid, &p.neg_inv_density, 4);
-        medium[i] = make_uint4(to_dref(p.boundary), nid, p.material, wk.owner_medium[i]);
+        medium[i] = make_uint4(to_dref(p.boundary), nid, p.material, wk.owner(wk.owner_medium[i]));
         ctx->id_medium[i] = p.prim_id;
     }
-    std::vector<float4> inst(static_cast<size_t>(s->n_instances) * 2);
-    for (uint32_t i = 0; i < s->n_instances; ++i) {
+    auto inst_record = [&](uint32_t i) {
         const rr_instance& p = s->instances[i];
-        inst[2 * i] = make_float4(u2f(p.kind), u2f(to_dref(p.child)), p.v[0], p.v[1]);
-        inst[2 * i + 1] = make_float4(p.v[2], u2f(wk.inst_depth[i]), 0.f, 0.f);
+        return p.kind == RR_INST_TRANSLATE ? make_float4(u2f(p.kind), p.v[0], p.v[1], p.v[2]) : make_float4(u2f(p.kind), p.v[0], p.v[1], 0.f);
+    };
+    std::vector<float4> inst(static_cast<size_t>(s->n_instances) * 2);
+    std::vector<float4> chain_rec(static_cast<size_t>(s->n_instances) * MAX_CHAIN, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t i = 0; i < s->n_instances; ++i) {
+        inst[2 * i] = inst_record(i);
+        inst[2 * i + 1] = make_float4(u2f(to_dref(s->instances[i].child)), u2f(wk.inst_depth[i]), 0.f, 0.f);
+        for (uint32_t k = 0; k < wk.inst_depth[i]; ++k) chain_rec[static_cast<size_t>(i) * MAX_CHAIN + k] = inst_record(wk.inst_chain[i * MAX_CHAIN + k]);
     }
     std::vector<uint2> list(s->n_lists);
     for (uint32_t i = 0; i < s->n_lists; ++i) list[i] = make_uint2(s->lists[i].first_child, s->lists[i].n_children);
@@ -934,7 +942,14 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevMaterial> materials(s->n_materials);
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         const rr_material& m = s->materials[i];
-        materials[i] = DevMaterial{m.type, m.texture, m.color[0], m.color[1], m.color[2], m.param, 0, 0};
+        DevMaterial dm{m.type, m.texture, m.color[0], m.color[1], m.color[2], m.param, 0, 0};
+        const bool textured = m.type == RR_MAT_LAMBERTIAN || m.type == RR_MAT_ISOTROPIC || m.type == RR_MAT_EMISSIVE;
+        if (textured && s->textures[m.texture].type == RR_TEX_SOLID) {
+            const rr_texture& t = s->textures[m.texture];
+            dm.r = t.color0[0], dm.g = t.color0[1], dm.b = t.color0[2];
+            dm.solid = 1;
+        }
+        materials[i] = dm;
     }
     std::vector<DevTexture> textures(s->n_textures);
     for (uint32_t i = 0; i < s->n_textures; ++i) {
@@ -982,7 +997,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &k.sphere_meta)) ||
         (rc = upload(mem, msphere, &d.msphere)) || (rc = upload(mem, rect, &d.rect)) || (rc = upload(mem, tri, &d.tri)) ||
         (rc = upload(mem, tri_meta, &k.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
-        (rc = upload(mem, inst, &d.inst)) || (rc = upload(mem, wk.inst_chain, &d.inst_chain)) || (rc = upload(mem, list, &d.list)) ||
+        (rc = upload(mem, inst, &d.inst)) || (rc = upload(mem, chain_rec, &d.chain_rec)) || (rc = upload(mem, list, &d.list)) ||
         (rc = upload(mem, child_refs, &d.child_refs)) || (rc = upload(mem, materials, &k.materials)) ||
         (rc = upload(mem, textures, &k.textures)) || (rc = upload(mem, perlin_vec, &k.perlin_vec)) ||
         (rc = upload(mem, perlin_perm, &k.perlin_perm)) || (rc = upload(mem, images, &k.images)) ||

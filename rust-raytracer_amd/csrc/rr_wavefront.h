@@ -25,6 +25,9 @@
 #ifndef RR_WF_TRAVERSE_WAVES_PER_SIMD
 #define RR_WF_TRAVERSE_WAVES_PER_SIMD 8
 #endif
+#ifndef RR_WF_SHADE_WAVES_PER_SIMD
+#define RR_WF_SHADE_WAVES_PER_SIMD 3
+#endif
 #ifndef RR_WF_REFILL_IDLE
 #define RR_WF_REFILL_IDLE 16  // a wave fetches new rays once this many of its lanes have none
 #endif
@@ -62,8 +65,9 @@ __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_
 // render.rs:95-98: every path of the batch starts at its camera ray with throughput one and full depth.
 __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState st, uint32_t* __restrict__ queue, WfCtl* ctl,
                                                  unsigned long long* counters) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < a.n_paths) {
+    // grid-stride: a bounded number of long-lived waves instead of one short wave per 64 paths
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < a.n_paths; p += step) {
         uint32_t pixel, sample;
         wf_path_key(a, p, pixel, sample);
         const uint32_t px = pixel % a.width, py = pixel / a.width;
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState 
         st.thr[p] = make_float4(1.f, 1.f, 1.f, 0.f);
         queue[p] = p;
     }
-    if (p == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[0].count = a.n_paths;
         ctl[0].cursor = 0;
         ctl[1].count = ctl[1].cursor = 0;
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     flush_counts(cnt, counters);
 }
 
-__global__ void __launch_bounds__(256) k_wf_shade(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue_in,
+__global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue_in,
                                                   const WfCtl* ctl_in, uint32_t* __restrict__ queue_out, WfCtl* ctl_out, WfCtl* ctl_clear,
                                                   unsigned long long* counters) {
     const uint32_t total = ctl_in->count;
