@@ -37,6 +37,12 @@ def short(name):
     return None
 
 
+def newest(pattern):
+    """gpurun merges every run into the same local directory: take the latest file only."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def counting(name):
     return "k_render<true" in name or "k_wf_traverse<true>" in name
 
@@ -49,14 +55,14 @@ def last_json_line(path):
 
 
 out = {"tag": tag, "workload": workload}
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"))
 bench = last_json_line(os.path.join(src, "bench_under_trace.json"))
 out["bench_under_trace"] = bench
 
 # per-kernel time of the timed steps (the warm-up step and the instrumented pass excluded)
-trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+trace = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if trace:
     rows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
     rows = [r for r in rows if short(r["Kernel_Name"])]
@@ -87,7 +93,7 @@ pmc_bench = None
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(d, "*", "*_counter_collection.csv"))
     if not files:
         continue
     if pmc_bench is None:
@@ -139,7 +145,7 @@ if pmc_bench:
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
     # percentages are per dispatch: report their mean over the dispatches of each kernel
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) if os.path.isdir(d) else []
+        files = newest(os.path.join(d, "*", "*_counter_collection.csv")) if os.path.isdir(d) else []
         for f in files:
             acc = collections.defaultdict(list)
             rows = [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"])]

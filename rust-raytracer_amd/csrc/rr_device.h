@@ -927,41 +927,55 @@ struct HitRec {
     uint32_t mat;
 };
 
+// Material and owner word of the primitive (or medium) a ref names.
+struct HitMeta {
+    uint32_t mat, owner;
+};
+__device__ __forceinline__ HitMeta hit_meta(const DevScene& sc, uint32_t ref) {
+    const uint32_t tag = dtag(ref), idx = didx(ref);
+    HitMeta m;
+    if (tag == RR_TAG_SPHERE) {
+        const uint2 v = sc.k->sphere_meta[idx];
+        m.mat = v.x, m.owner = v.y;
+    } else if (tag == RR_TAG_RECT) {
+        const float4 v = sc.rect[2 * idx + 1];
+        m.mat = __float_as_uint(v.z), m.owner = __float_as_uint(v.w);
+    } else if (tag == RR_TAG_TRIANGLE) {
+        const uint2 v = sc.k->tri_meta[idx];
+        m.mat = v.x, m.owner = v.y;
+    } else if (tag == RR_TAG_MOVING_SPHERE) {
+        const float4 v = sc.msphere[3 * idx + 2];
+        m.mat = __float_as_uint(v.y), m.owner = __float_as_uint(v.z);
+    } else {  // medium
+        const uint4 v = sc.medium[idx];
+        m.mat = v.z, m.owner = v.w;
+    }
+    return m;
+}
+
 // Rebuild the HitRecord (material.rs:8-38) the reference would have returned for the
 // winning (t, primitive): evaluate the primitive in its own space, then walk the
-// enclosing instances outwards applying their hit transforms.
-__device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref,
+// enclosing instances outwards applying their hit transforms.  Everything fetched here is
+// addressed by (ref, meta) alone, so the loads go out together.
+__device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta,
                                                   bool want_uv) {
     HitRec h;
     h.t = t;
     h.u = 0.0f;
     h.v = 0.0f;
+    h.mat = meta.mat;
     const uint32_t tag = dtag(ref), idx = didx(ref);
-    uint32_t owner;
-    float4 r0, r1;  // record words reused below
+    const uint32_t owner = meta.owner;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;  // record words reused below
     if (tag == RR_TAG_SPHERE) {
-        const uint2 m = sc.k->sphere_meta[idx];
-        h.mat = m.x;
-        owner = m.y;
         r0 = sc.sphere[idx];
     } else if (tag == RR_TAG_RECT) {
         r0 = sc.rect[2 * idx];
         r1 = sc.rect[2 * idx + 1];
-        h.mat = __float_as_uint(r1.z);
-        owner = __float_as_uint(r1.w);
     } else if (tag == RR_TAG_TRIANGLE) {
-        const uint2 m = sc.k->tri_meta[idx];
-        h.mat = m.x;
-        owner = m.y;
         r0 = sc.tri[3 * idx + 2];
     } else if (tag == RR_TAG_MOVING_SPHERE) {
         r0 = sc.msphere[3 * idx + 2];
-        h.mat = __float_as_uint(r0.y);
-        owner = __float_as_uint(r0.z);
-    } else {  // medium
-        const uint4 m = sc.medium[idx];
-        h.mat = m.z;
-        owner = m.w;
     }
     // the ray in the primitive's space; the directions inside the two outermost instances are kept for the way back
     const uint32_t depth = owner_depth(owner);
@@ -1042,7 +1056,7 @@ __device__ __forceinline__ int floor_to_int_sat(float f) {
     return static_cast<int>(f);
 }
 
-__device__ inline float perlin_noise(const DevScene& sc, uint32_t table, f3 p) {  // perlin.rs:47-86
+__device__ __forceinline__ float perlin_noise(const DevScene& sc, uint32_t table, f3 p) {  // perlin.rs:47-86
     const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     const int i = floor_to_int_sat(fx), j = floor_to_int_sat(fy), k = floor_to_int_sat(fz);
@@ -1067,7 +1081,7 @@ __device__ inline float perlin_noise(const DevScene& sc, uint32_t table, f3 p) {
     return accum;
 }
 
-__device__ inline float perlin_turb(const DevScene& sc, uint32_t table, f3 p, uint32_t depth) {  // perlin.rs:87-98
+__device__ __forceinline__ float perlin_turb(const DevScene& sc, uint32_t table, f3 p, uint32_t depth) {  // perlin.rs:87-98
     float accum = 0.0f, weight = 1.0f;
     f3 tp = p;
     for (uint32_t i = 0; i < depth; ++i) {
@@ -1089,7 +1103,10 @@ __device__ __forceinline__ uint32_t f32_as_u32_sat(float f) {  // Rust `as u32`
     return static_cast<uint32_t>(f);
 }
 
-__device__ inline f3 texture_color(const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
+__device__ __forceinline__ f3 texture_color(const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
+#ifdef RR_ABLATE_TEXTURES
+    return mk3(u, v, p.x);
+#endif
     const DevTexture& t = sc.k->textures[tex];
     const uint32_t type = t.type;
     if (type == RR_TEX_SOLID) return mk3(t.c0[0], t.c0[1], t.c0[2]);
@@ -1163,7 +1180,8 @@ struct Bounce {
     f3 weight;
     f3 terminal;
 };
-__device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, Rng& g, Bounce& out) {
+__device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta, Rng& g,
+                                      Bounce& out) {
     if (ref == NONE) {
         out.terminal = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
         return false;
@@ -1173,9 +1191,9 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     {
         // material id is needed before reconstruct can know about uv, so reconstruct asks for
         // uv whenever the scene has images at all
-        rec = reconstruct_hit(sc, wo, wd, time, t, ref, sc.k->images != nullptr);
+        rec = reconstruct_hit(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
     }
-    const DevMaterial m = sc.k->materials[rec.mat];
+    const DevMaterial m = sc.k->materials[meta.mat];
     f3 attenuation;
     const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
             go_on = false;
             b.terminal = mk3(t, __uint_as_float(ref), g.random());
 #else
-            go_on = shade(sc, ro, rd, time, t, ref, g, b);
+            go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
 #endif
             if (go_on) {
                 ro = b.o;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, c
         for (int k = 0; k < 12; ++k) of[k] = 0.f;
         return;
     }
-    const HitRec h = reconstruct_hit(sc, o, d, time, t, ref, true);
+    const HitRec h = reconstruct_hit(sc, o, d, time, t, ref, hit_meta(sc, ref), true);
     of[0] = h.t;
     of[1] = h.p.x, of[2] = h.p.y, of[3] = h.p.z;
     of[4] = h.n.x, of[5] = h.n.y, of[6] = h.n.z;

@@ -28,6 +28,7 @@
 #ifndef RR_WF_SHADE_WAVES_PER_SIMD
 #define RR_WF_SHADE_WAVES_PER_SIMD 3
 #endif
+constexpr uint32_t WF_STAGE = 1024;  // queue entries a shading wave collects before it appends them
 #ifndef RR_WF_REFILL_IDLE
 #define RR_WF_REFILL_IDLE 16  // a wave fetches new rays once this many of its lanes have none
 #endif
@@ -35,8 +36,9 @@
 struct WfState {     // one entry per path in each array
     float4* ray_o;   // (origin.xyz, time)
     float4* ray_d;   // (direction.xyz, ray_color depth left)
-    float4* thr;     // (throughput.xyz, -) while the path lives, its sample value once it has ended
-    uint4* hit;      // (t, primitive ref, draws the traversal took from the bounce's stream, -)
+    float4* thr;     // (throughput.xyz, draws the traversal took from the bounce's random stream) while the path lives,
+                     // its sample value once it has ended
+    uint4* hit;      // (t, primitive ref, material, owner word) of the closest hit, ref NONE for a miss
 };
 struct WfCtl {
     uint32_t count;   // entries in the queue
@@ -147,18 +149,32 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     bool active = false;
     bool exhausted = total == 0;  // wave-uniform: the queue has no unclaimed entries left
     uint32_t p = 0, draws = 0;
+    // A wave claims queue entries a chunk at a time and hands them to its lanes as they fall idle:
+    // one atomic on the shared cursor per chunk, not per refill (atomics on one address serialise,
+    // and at a few nanoseconds each a claim per refill would cost as much as the traversal itself).
+    // Chunks are sized so that every wave makes several claims, which evens out the finish.
+    const uint32_t n_waves = gridDim.x * (blockDim.x / 64u);
+    const uint32_t chunk = min(max(total / (n_waves * 8u), 64u), 4096u);
+    uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
     // Every lane leaves through the same wave-wide vote, after the queue is drained and the last
     // ray of the wave has finished.
     for (;;) {
         const uint64_t idle = __ballot(!active);
         if (!exhausted && __popcll(idle) >= RR_WF_REFILL_IDLE) {
+            if (chunk_pos == chunk_end) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(&ctl->cursor, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                chunk_pos = min(base, total);
+                chunk_end = min(base + chunk, total);
+            }
             const uint32_t want = static_cast<uint32_t>(__popcll(idle));
-            uint32_t base = 0;
-            if ((threadIdx.x & 63u) == 0) base = atomicAdd(&ctl->cursor, want);
-            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t take = min(want, chunk_end - chunk_pos);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
-            const uint32_t entry = base + rank;
-            if (!active && base < total && entry < total) {
+            const uint32_t entry = chunk_pos + rank;
+            chunk_pos += take;
+            exhausted = chunk_pos == chunk_end && chunk_end == total;  // the cursor only grows: nothing is left for anyone
+            if (!active && rank < take) {
                 p = queue[entry];
                 const float4 ro = st.ray_o[p], rd = st.ray_d[p];
                 if (__float_as_uint(rd.w) != 0u) {  // ray_color with depth 0 intersects nothing (render.rs:16)
@@ -167,7 +183,6 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                     active = true;
                 }
             }
-            exhausted = base >= total || total - base <= want;
         }
         if (!__any(active)) {
             if (exhausted) break;
@@ -179,7 +194,10 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
             trav_step<COUNT>(sc, m, world, draw, stk, stride, cnt);
             draws = draw.n;
             if (m.finished()) {
-                st.hit[p] = make_uint4(__float_as_uint(m.tmax), m.cur, draws, 0u);
+                // the hit's material and owner are fetched here, where the latency hides behind other rays' work
+                const HitMeta hm = m.cur == NONE ? HitMeta{0u, 0u} : hit_meta(sc, m.cur);
+                st.hit[p] = make_uint4(__float_as_uint(m.tmax), m.cur, hm.mat, hm.owner);
+                if (draws != 0) reinterpret_cast<uint32_t*>(&st.thr[p])[3] = draws;
                 active = false;
             }
         }
@@ -193,13 +211,40 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
     const uint32_t total = ctl_in->count;
     const uint32_t step = gridDim.x * blockDim.x;
     Counts cnt = {0, 0, 0, 0, 0, 0, 0};
-    // whole waves iterate together (step is a multiple of 64), so the votes below are well defined
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; (i & ~63u) < total; i += step) {
+    // Paths that go on are collected per wave in LDS and appended to the next queue a batch at a time:
+    // one atomic on the shared counter per WF_STAGE-64 or more entries instead of one per wave iteration.
+    __shared__ uint32_t stage_all[4][WF_STAGE];
+    uint32_t* stage = stage_all[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t staged = 0;  // wave-uniform
+    auto flush = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctl_out->count, staged);
+        base = __builtin_amdgcn_readfirstlane(base);
+        __builtin_amdgcn_wave_barrier();  // the lanes read what other lanes of the wave have staged
+        for (uint32_t k = lane; k < staged; k += 64u) queue_out[base + k] = stage[k];
+        __builtin_amdgcn_wave_barrier();
+        staged = 0;
+    };
+    // Whole waves iterate together (step is a multiple of 64), so the votes below are well defined.
+    // The loop is a three-stage pipeline per lane — queue entry two iterations ahead, path state one
+    // iteration ahead, shading now — so that the loads of the next paths are in flight while this one
+    // is shaded: the kernel is bound by the latency of its dependent loads, not by their volume.
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p1 = i < total ? queue_in[i] : 0u;
+    uint32_t p2 = (i + step < total && i + step > i) ? queue_in[i + step] : 0u;
+    float4 qo1 = st.ray_o[p1], qd1 = st.ray_d[p1], qt1 = st.thr[p1];
+    uint4 qh1 = st.hit[p1];
+    for (; (i & ~63u) < total; i += step) {
         bool keep = false;
-        uint32_t p = 0;
+        const uint32_t p = p1;
+        const float4 qo = qo1, qd = qd1, qt = qt1;
+        const uint4 h = qh1;
+        p1 = p2;
+        qo1 = st.ray_o[p1], qd1 = st.ray_d[p1], qt1 = st.thr[p1], qh1 = st.hit[p1];  // entry 0 when there is no next path: harmless
+        const uint32_t i2 = i + 2u * step;
+        p2 = (i2 < total && i2 > i) ? queue_in[i2] : 0u;
         if (i < total) {
-            p = queue_in[i];
-            const float4 qo = st.ray_o[p], qd = st.ray_d[p], qt = st.thr[p];
             const f3 ro = mk3(qo.x, qo.y, qo.z), rd = mk3(qd.x, qd.y, qd.z);
             f3 thr = mk3(qt.x, qt.y, qt.z);
             const float time = qo.w;
@@ -207,15 +252,36 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
             f3 terminal = mk3(0.f, 0.f, 0.f);
             if (depth_left != 0) {  // one ray_color call (render.rs:15-41) from its scene.intersect on
                 cnt.rays++;
-                const uint4 h = st.hit[p];
                 uint32_t pixel, sample;
                 wf_path_key(a, p, pixel, sample);
                 Rng g;
                 g.start(a.seed, pixel, sample, a.max_depth - depth_left);
-                g.n = h.z;
-                if (h.z & 3u) g.refill();
+                g.n = __float_as_uint(qt.w);
+                if (g.n & 3u) g.refill();
                 Bounce b;
-                keep = shade(sc, ro, rd, time, __uint_as_float(h.x), h.y, g, b);
+#ifdef RR_ABLATE_WF_SHADE  // timing-only builds: wrong images, price the sections of the kernel
+                keep = h.y != NONE && (p & 3u) != 0u;
+                b.o = ro + rd * __uint_as_float(h.x), b.d = rd, b.weight = mk3(0.5f, 0.5f, g.random()), b.terminal = b.weight;
+#if RR_ABLATE_WF_SHADE >= 2
+                if (h.y != NONE) {
+                    const HitRec rec = reconstruct_hit(sc, ro, rd, time, __uint_as_float(h.x), h.y, HitMeta{h.z, h.w}, false);
+                    b.o = rec.p, b.d = rec.n;
+#if RR_ABLATE_WF_SHADE >= 3
+                    const DevMaterial mm = sc.k->materials[h.z];
+                    b.weight = mk3(mm.r, mm.g, mm.b);
+#endif
+#if RR_ABLATE_WF_SHADE >= 4
+                    const f3 cd = random_cosine_direction(g);
+                    b.d = b.d + cd;
+#endif
+#if RR_ABLATE_WF_SHADE >= 5
+                    b.weight.x = light_pdf_value(sc, rec.p, b.d);
+#endif
+                }
+#endif
+#else
+                keep = shade(sc, ro, rd, time, __uint_as_float(h.x), h.y, HitMeta{h.z, h.w}, g, b);
+#endif
                 if (keep) {
                     thr = thr * b.weight;
                     depth_left -= 1;
@@ -233,13 +299,13 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
         }
         const uint64_t mask = __ballot(keep);
         if (mask) {
-            uint32_t base = 0;
-            if ((threadIdx.x & 63u) == 0) base = atomicAdd(&ctl_out->count, static_cast<uint32_t>(__popcll(mask)));
-            base = __builtin_amdgcn_readfirstlane(base);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-            if (keep) queue_out[base + rank] = p;
+            if (keep) stage[staged + rank] = p;
+            staged += static_cast<uint32_t>(__popcll(mask));
+            if (staged > WF_STAGE - 64u) flush();
         }
     }
+    if (staged != 0) flush();
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the queue two bounces back is free again
         ctl_clear->count = 0;
         ctl_clear->cursor = 0;
