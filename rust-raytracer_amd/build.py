@@ -38,7 +38,7 @@ def _headers():
 
 def build_hip(force=False):
     src = [os.path.join(CSRC, "rr_hip.hip")]
-    deps = src + [os.path.join(CSRC, "rr_device.h")] + _headers()
+    deps = src + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + _headers()
     if force or _stale(abi.HIP_LIB, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc] + HIPCC_FLAGS + ["-o", abi.HIP_LIB] + src)

@@ -451,7 +451,7 @@ struct Trav {
         sp = 0;
         hitf = false;
     }
-    __device__ __forceinline__ bool finished() const { return node == NONE; }  // holds between steps only
+    __device__ __forceinline__ bool finished() const { return node == NONE && sp == 0; }
 };
 
 // What the machine needs only now and then comes through two small providers, so that a kernel
@@ -459,15 +459,18 @@ struct Trav {
 //   World: ray(wo, wd) — the ray in world space; time() — the ray's time
 //   Draw:  random()    — the next f32 of the path's random stream
 //
-// One step: evaluate m.node if there is one, then return to callers until one of them names the
-// next node or the outermost call has returned (m.finished()).
-template <bool COUNT, class World, class Draw>
-__device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk,
-                                          uint32_t stride, Counts& cnt) {
-    // A step has three phases, each taken by every lane whose state asks for it: a BVH node, then
-    // whatever else the lane is at (possibly the child the node phase has just chosen), then the
-    // returns.  A ray alternating between nodes and leaves advances through two records per step
-    // and the wave executes neither phase for the sake of a few lanes only.
+// The machine advances in three kinds of moves, each a function below:
+//   trav_node   m.node is a BVH node: box test, frame push, first child
+//   trav_leaf   m.node is anything else: primitive tests, or the entry of a list, instance or medium
+//   trav_pop    m.node is NONE: return to the innermost caller, which names the next node or has none left
+// The machine is finished when m.node is NONE and the stack is empty.  A kernel is
+// free to schedule the moves of its 64 lanes as it likes (all lanes at nodes first, leaves when
+// enough lanes have one) as long as each lane's own sequence is node/leaf followed by pop.
+__device__ __forceinline__ bool trav_at_node(const Trav& m) { return m.node != NONE && dtag(m.node) == RR_TAG_BVH; }
+__device__ __forceinline__ bool trav_at_leaf(const Trav& m) { return m.node != NONE && dtag(m.node) != RR_TAG_BVH; }
+
+template <bool COUNT>
+__device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ BVH node
     if (m.node != NONE && dtag(m.node) == RR_TAG_BVH) {
         const uint32_t idx = didx(m.node);
@@ -532,6 +535,10 @@ __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const Wor
             }
         }
     }
+}
+
+template <bool COUNT, class World>
+__device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const World& world, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ primitive, list, instance or medium
     if (m.node != NONE && dtag(m.node) != RR_TAG_BVH) {
         const uint32_t node = m.node;
@@ -639,8 +646,16 @@ __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const Wor
             m.node = sc.medium[idx].x;
         }
     }
+}
+
+template <bool COUNT, class World, class Draw>
+__device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk, uint32_t stride,
+                                         Counts& cnt) {
     // ------------------------------------------- return to the callers
-    while (m.node == NONE && m.sp != 0) {
+    // One return per move: a lane whose caller has nothing left for it either returns again in its next
+    // move.  (Returning in a loop here keeps the whole wave waiting for its few lanes with long chains
+    // of returns; measured 15 % slower.)
+    if (m.node == NONE && m.sp != 0) {
         const uint32_t fw = stk[(m.sp - 1) * stride];
         const uint32_t kind = dtag(fw), idx = didx(fw);
         if (kind <= RR_TAG_LIST) {
@@ -713,6 +728,16 @@ __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const Wor
             }
         }
     }
+}
+
+// One step of a single lane's sequence: a node if the lane is at one, then whatever it is at
+// after that, then the returns.
+template <bool COUNT, class World, class Draw>
+__device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk,
+                                          uint32_t stride, Counts& cnt) {
+    trav_node<COUNT>(sc, m, stk, stride, cnt);
+    trav_leaf<COUNT>(sc, m, world, stk, stride, cnt);
+    trav_pop<COUNT>(sc, m, world, draw, stk, stride, cnt);
 }
 
 // Providers for a kernel that holds the world ray and the path's generator in registers.
