@@ -36,6 +36,7 @@ WORKLOADS = {
     "suzanne": ("suzanne", 800, 800, 1000, 100),
     "final": ("final", 800, 800, 10000, 50),
     "spheres": ("spheres", 400, 225, 100, 50),
+    "mesh": ("mesh", 3840, 2160, 4096, 50),   # 1M-triangle height field + 100k spheres (configs[4]); use --spp for a short run
 }
 
 
@@ -179,8 +180,13 @@ def main():
         assert total_samples == samples_per_step * args.steps, (total_samples, samples_per_step, args.steps)
         value = total_samples / elapsed / 1e6
 
-        # per-ray work of the algorithm, from an instrumented pass outside the timed region
-        pc = device.make_params(W, H, K * world * 4, n_slices=K * world, max_depth=depth, seed=args.seed,
+        # per-ray work of the algorithm, from an instrumented pass outside the timed region: the counting
+        # kernels make every visit the reference makes, which on big BVHs is orders of magnitude more than the
+        # production kernels do, so the pass renders a reduced image (per-ray averages do not depend on it)
+        scale = min(1.0, (2.0e6 / (W * H * K * 4.0)) ** 0.5)
+        Wc, Hc = max(16, int(W * scale)), max(16, int(H * scale))
+        print(f"# counting pass: {Wc}x{Hc}, {K * 4} spp", file=sys.stderr, flush=True)
+        pc = device.make_params(Wc, Hc, K * world * 4, n_slices=K * world, max_depth=depth, seed=args.seed,
                                 slice_begin=0, slice_end=K, flags=1)
         c2 = torch.zeros(8, dtype=torch.int64, device=dev)
         ctx.render_device(pc, slice_sums.data_ptr(), None, None, c2.data_ptr(), stream)

@@ -260,6 +260,10 @@ typedef struct rr_scene_info {
     uint64_t device_bytes;   /* bytes of scene data resident in HBM      */
     uint32_t n_prims;        /* spheres + moving spheres + rects + triangles */
     uint32_t wavefront;      /* 1: rendered by the wavefront pipeline unless RR_FLAG_PERSISTENT is set (the scene has BVH nodes) */
+    uint32_t bvh_nodes_by_class[4]; /* how the production kernels treat the BVH nodes: [0] no box, [1] exactly as the
+                                       reference (a constant medium below, or a box that does not hold what is below),
+                                       [2] redundant visits skipped and subtrees culled against [t_min,t_max],
+                                       [3] the same against [0,inf) (triangles below)                              */
 } rr_scene_info;
 
 typedef struct rr_context rr_context;

@@ -843,6 +843,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // record's length: the arrays it reads that way end in three words of padding and are never empty.
     constexpr size_t PAD = 3;
     std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2 + PAD);
+    uint32_t class_count[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
         const rr_bvh_node& n = s->bvh_nodes[i];
         bvh[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], u2f(to_dref(n.left, n.axis)));
@@ -860,6 +861,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
             if (holds) cls = b.has_tri ? BVH_CLASS_CULL_ANY_T : BVH_CLASS_CULL_RANGE;
         }
         bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, cls)));
+        if (wk.seen[RR_TAG_BVH][i]) class_count[cls]++;
     }
     std::vector<float4> sphere(s->n_spheres + PAD);
     std::vector<uint2> sphere_meta(s->n_spheres);
@@ -1036,6 +1038,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
     ctx->info.wavefront = ctx->has_subtrees ? 1u : 0u;
+    for (int c = 0; c < 4; ++c) ctx->info.bvh_nodes_by_class[c] = class_count[c];
     ctx->has_scene = true;
     return RR_OK;
 }
