@@ -832,7 +832,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
 // w2..w7 = six f32 operands.
 constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
                    OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
-                   OP_MED_MID = 13, OP_MED_END = 14;
+                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15;
 constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
 
 struct Op {
@@ -878,6 +878,17 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
             hit &= live;
             tmax = hit ? t : tmax;
             cur = hit ? op.ref : cur;
+        } else if (code == OP_CUBOID) {  // collider.rs:428-430: the six sides in the constructor's order (collider.rs:419-426)
+            if (COUNT && live) cnt.rect_tests += 6;
+            float t;
+            uint32_t side = NONE;
+            if (test_rect_axis<RR_RECT_XY>(op.f0, op.f3, op.f1, op.f4, op.f5, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 0;
+            if (test_rect_axis<RR_RECT_XY>(op.f0, op.f3, op.f1, op.f4, op.f2, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 1;
+            if (test_rect_axis<RR_RECT_XZ>(op.f0, op.f3, op.f2, op.f5, op.f4, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 2;
+            if (test_rect_axis<RR_RECT_XZ>(op.f0, op.f3, op.f2, op.f5, op.f1, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 3;
+            if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f3, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 4;
+            if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f0, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 5;
+            if (live && side != NONE) cur = op.ref + side;
         } else if (code == OP_RESET) {
             o = wo;
             d = wd;

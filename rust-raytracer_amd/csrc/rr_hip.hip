@@ -493,10 +493,25 @@ struct Walker {
 
 uint32_t to_dref(uint32_t ref, uint32_t extra = 0) { return dref(RR_REF_TAG(ref), RR_REF_INDEX(ref), extra); }
 
+// Corners of a cuboid whose six rects are exactly what Cuboid::new (collider.rs:419-426) makes of two
+// corners, in its order; false for any other six rects.
+bool cuboid_corners(const rr_flat_scene& s, uint32_t ci, float p0[3], float p1[3]) {
+    const rr_rect* r = &s.rects[s.cuboids[ci].first_rect];
+    p0[0] = r[0].a0, p0[1] = r[0].b0, p0[2] = r[1].k;
+    p1[0] = r[0].a1, p1[1] = r[0].b1, p1[2] = r[0].k;
+    auto is = [](const rr_rect& q, uint32_t axis, float a0, float a1, float b0, float b1, float k) {
+        const float have[5] = {q.a0, q.a1, q.b0, q.b1, q.k}, want[5] = {a0, a1, b0, b1, k};
+        return q.axis == axis && std::memcmp(have, want, sizeof(have)) == 0;
+    };
+    return is(r[0], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p1[2]) && is(r[1], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p0[2]) &&
+           is(r[2], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p1[1]) && is(r[3], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p0[1]) &&
+           is(r[4], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p1[0]) && is(r[5], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p0[0]);
+}
+
 // ---------------------------------------------------------- scene program
 // Compiles the ray-independent part of the (already validated) tree into the op array that
 // rrdev::traverse interprets: lists are unrolled in order, instances become transform ops on
-// the current ray space, cuboids become their six rect ops, a medium becomes begin / boundary /
+// the current ray space, cuboids become one op (or their six rect ops if they are not the constructor's), a medium becomes begin / boundary /
 // mid / boundary / end, and every BVH node (or a medium nested in a medium's boundary) becomes
 // one OP_SUBTREE for the per-lane machine.
 struct ProgramBuilder {
@@ -556,10 +571,15 @@ struct ProgramBuilder {
                 ensure_space();
                 rect_op(idx);
                 break;
-            case RR_TAG_CUBOID:
+            case RR_TAG_CUBOID: {
                 ensure_space();
-                for (uint32_t i = 0; i < 6; ++i) rect_op(s.cuboids[idx].first_rect + i);
+                float p0[3], p1[3];
+                if (cuboid_corners(s, idx, p0, p1))  // all six sides in one op, from the corners
+                    ops.push_back(make(OP_CUBOID, dref(RR_TAG_RECT, s.cuboids[idx].first_rect), p0[0], p0[1], p0[2], p1[0], p1[1], p1[2]));
+                else
+                    for (uint32_t i = 0; i < 6; ++i) rect_op(s.cuboids[idx].first_rect + i);
                 break;
+            }
             case RR_TAG_SPHERE: {
                 ensure_space();
                 const rr_sphere& p = s.spheres[idx];
@@ -905,15 +925,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         // Corners of the box, if the six rects are exactly what Cuboid::new (collider.rs:419-426)
         // makes of two corners; the machine then tests the sides from these 32 bytes alone.
         if (!wk.seen[RR_TAG_CUBOID][i]) continue;  // not part of the tree: never visited, range never checked
-        const rr_rect* r = &s->rects[s->cuboids[i].first_rect];
-        const float p0[3] = {r[0].a0, r[0].b0, r[1].k}, p1[3] = {r[0].a1, r[0].b1, r[0].k};
-        auto is = [](const rr_rect& q, uint32_t axis, float a0, float a1, float b0, float b1, float k) {
-            const float have[5] = {q.a0, q.a1, q.b0, q.b1, q.k}, want[5] = {a0, a1, b0, b1, k};
-            return q.axis == axis && std::memcmp(have, want, sizeof(have)) == 0;
-        };
-        const bool canonical = is(r[0], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p1[2]) && is(r[1], RR_RECT_XY, p0[0], p1[0], p0[1], p1[1], p0[2]) &&
-                               is(r[2], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p1[1]) && is(r[3], RR_RECT_XZ, p0[0], p1[0], p0[2], p1[2], p0[1]) &&
-                               is(r[4], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p1[0]) && is(r[5], RR_RECT_YZ, p0[1], p1[1], p0[2], p1[2], p0[0]);
+        float p0[3], p1[3];
+        const bool canonical = cuboid_corners(*s, i, p0, p1);
         cuboid[2 * i] = make_float4(p0[0], p0[1], p0[2], u2f(s->cuboids[i].first_rect));
         cuboid[2 * i + 1] = make_float4(p1[0], p1[1], p1[2], u2f(canonical ? 1u : 0u));
     }
