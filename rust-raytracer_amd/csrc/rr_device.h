@@ -1056,8 +1056,10 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
         } else {
             a = o.y + t * d.y, b = o.z + t * d.z, outn = mk3(1.0f, 0.0f, 0.0f);
         }
-        h.u = (a - r0.x) / (r0.y - r0.x);
-        h.v = (b - r0.z) / (r0.w - r0.z);
+        if (want_uv) {  // only image textures read u, v (texture.rs:84-94)
+            h.u = (a - r0.x) / (r0.y - r0.x);
+            h.v = (b - r0.z) / (r0.w - r0.z);
+        }
         h.front = dot3(d, outn) < 0.0f;
         h.n = h.front ? outn : neg3(outn);
     } else if (tag == RR_TAG_TRIANGLE) {
