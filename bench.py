@@ -221,7 +221,9 @@ def main():
             try:
                 dd = json.load(open(path))["derived"]
                 kk = "k_wf_traverse<false>" if info["wavefront"] else "k_render<false>"
-                measured = {"valu_busy_pct": dd.get("VALUBusy_mean_per_dispatch", {}).get(kk),
+                measured = {"kernel": kk, "valu_busy_pct_largest_dispatch": dd.get("VALUBusy_first_dispatch", {}).get(kk),
+                            "valu_lane_utilization_pct_largest_dispatch": dd.get("VALUUtilization_first_dispatch", {}).get(kk),
+                            "waves_per_cu_largest_dispatch": dd.get("MeanOccupancyPerCU_first_dispatch", {}).get(kk),
                             "active_lanes_per_valu_inst": dd.get("active_lanes_per_valu_inst"),
                             "valu_insts_per_wave_ray": dd.get("valu_insts_per_wave_ray"), "source": os.path.basename(path)}
             except Exception:

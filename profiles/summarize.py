@@ -151,11 +151,14 @@ if pmc_bench:
             rows = [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"])]
             ids = [int(r["Dispatch_Id"]) for r in rows if counting(r["Kernel_Name"])]
             cut = min(ids) if ids else 1 << 62
-            for r in rows:
+            for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
                 if r["Counter_Name"] in ("MeanOccupancyPerCU", "VALUUtilization", "VALUBusy") and int(r["Dispatch_Id"]) < cut:
                     acc[(r["Counter_Name"], short(r["Kernel_Name"]))].append(float(r["Counter_Value"]))
             for (name, k), v in acc.items():
                 derived.setdefault(name + "_mean_per_dispatch", {})[k] = round(sum(v) / len(v), 3)
+                # the first dispatch of a wavefront kernel is the largest (every path of the batch is alive): the mean over
+                # dispatches is dominated by the many near-empty launches at the end of a bounce loop
+                derived.setdefault(name + "_first_dispatch", {})[k] = round(v[0], 3)
     out["derived"] = derived
 json.dump(out, open(os.path.join(dst, f"{tag}_{workload}_summary.json"), "w"), indent=1)
 print(json.dumps(out.get("derived", {}), indent=1))
