@@ -232,6 +232,9 @@ typedef struct rr_render_params {
  * queue of live paths), used for scenes with them.  These flags override the choice.       */
 #define RR_FLAG_PERSISTENT 2u
 #define RR_FLAG_WAVEFRONT 4u
+/* The wavefront pipeline hands the last few paths of a batch to a kernel that runs each of them to its end;
+ * this flag keeps it to bounce-by-bounce launches throughout (for tests: the result is the same).      */
+#define RR_FLAG_NO_FINISH_KERNEL 8u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */

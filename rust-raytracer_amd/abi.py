@@ -21,6 +21,7 @@ TEX_SOLID, TEX_CHECKERED, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 FLAG_COUNTERS = 1
 FLAG_PERSISTENT = 2
 FLAG_WAVEFRONT = 4
+FLAG_NO_FINISH_KERNEL = 8
 PERLIN_POINTS = 256
 
 

@@ -667,7 +667,7 @@ int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t n_sl, ui
 // ends when no path is left, followed by the in-order accumulation of the batch.  How many
 // bounces a batch takes is only known on the device, so the host reads the live-path count back
 // every few bounces and this function returns when the last batch's paths have ended.
-int render_wavefront(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream) {
+int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, float* sums, unsigned long long* counters, hipStream_t stream) {
     // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path); the
     // short low-occupancy tail at the end of a bounce loop is paid once per batch.
     size_t free_b = 0, total_b = 0;
@@ -702,8 +702,13 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, float* sums, unsigne
     int grid_full = 0;
     if (int rc = launch_dims(ctx, lds, kernel, &grid_full)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
+    int grid_finish = 0;
+    if (int rc = launch_dims(ctx, lds, count ? reinterpret_cast<const void*>(&k_wf_finish<true>) : reinterpret_cast<const void*>(&k_wf_finish<false>), &grid_finish))
+        return rc;
 
-    constexpr uint32_t POLL_EVERY = 8;
+    // The host learns the number of live paths by reading it back (a stream synchronisation) after every bounce
+    // from the fourth on; when few are left, one launch of k_wf_finish runs them to their ends.
+    constexpr uint32_t POLL_FROM = 3, FINISH_FRACTION = 64, FINISH_MIN = 1u << 16;
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
         a.s0 = s0;
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
@@ -726,11 +731,20 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, float* sums, unsigne
                     hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
                 hipLaunchKernelGGL(k_wf_shade, dim3(grid_s), dim3(256), 0, stream, ctx->sc, a, st, q_in, c_in, q_out, c_out, c_clear, counters);
                 HIP_TRY(hipGetLastError());
-                if ((it + 1u) % POLL_EVERY == 0 && it != a.max_depth) {
+                if (it >= POLL_FROM && it != a.max_depth) {
                     HIP_TRY(hipMemcpyAsync(ctx->wf_host_count, &c_out->count, 4, hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
                     live = *ctx->wf_host_count;
                     if (live == 0) break;
+                    if (live <= std::max(a.n_paths / FINISH_FRACTION, FINISH_MIN) && !(flags & RR_FLAG_NO_FINISH_KERNEL)) {
+                        const uint32_t grid_f = std::min<uint32_t>((live + 255u) / 256u, static_cast<uint32_t>(grid_finish));
+                        if (count)
+                            hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid_f), dim3(256), lds, stream, ctx->sc, a, st, q_out, c_out, ctx->root, counters);
+                        else
+                            hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid_f), dim3(256), lds, stream, ctx->sc, a, st, q_out, c_out, ctx->root, counters);
+                        HIP_TRY(hipGetLastError());
+                        break;
+                    }
                 }
             }
         }
@@ -1158,7 +1172,7 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.slice_first = p->slice_begin + s0;
             w.slice_out = s0;
-            if (int rc = render_wavefront(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
+            if (int rc = render_wavefront(ctx, w, count, p->flags, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
                 return rc;
         }
         HIP_TRY(hipEventRecord(ctx->ev1, stream));

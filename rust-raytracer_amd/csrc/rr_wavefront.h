@@ -328,3 +328,47 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
     }
     flush_counts(cnt, counters);
 }
+
+// The stragglers of a batch.  Once few paths are left, a bounce costs two launches that each last as long
+// as their slowest ray while the chip idles; this kernel runs every remaining path to its end instead, a
+// lane per path, bounce after bounce like k_render (same machine, same shade, same random streams).
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_wf_finish(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
+                                                   const WfCtl* ctl, uint32_t root, unsigned long long* counters) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint32_t total = ctl->count;
+    const uint32_t step = gridDim.x * blockDim.x;
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const uint32_t p = queue[i];
+        const float4 qo = st.ray_o[p], qd = st.ray_d[p], qt = st.thr[p];
+        f3 ro = mk3(qo.x, qo.y, qo.z), rd = mk3(qd.x, qd.y, qd.z), thr = mk3(qt.x, qt.y, qt.z);
+        const float time = qo.w;
+        uint32_t depth_left = __float_as_uint(qd.w);
+        uint32_t pixel, sample;
+        wf_path_key(a, p, pixel, sample);
+        f3 terminal = mk3(0.f, 0.f, 0.f);
+        while (depth_left != 0) {  // one ray_color call (render.rs:15-41) per turn
+            cnt.rays++;
+            Rng g;
+            g.start(a.seed, pixel, sample, a.max_depth - depth_left);
+            float t = kF32Max;
+            uint32_t ref = NONE;
+            machine<COUNT>(sc, root, ro, rd, ro, rd, time, 0.001f, t, ref, g, stk, stride, cnt);
+            Bounce b;
+            if (!shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b)) {
+                terminal = b.terminal;
+                break;
+            }
+            ro = b.o;
+            rd = b.d;
+            thr = thr * b.weight;
+            depth_left -= 1;
+        }
+        const f3 c = thr * terminal;  // the sample's value (render.rs:99 adds it to the pixel)
+        st.thr[p] = make_float4(c.x, c.y, c.z, 0.f);
+    }
+    flush_counts(cnt, counters);
+}

@@ -192,9 +192,9 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
     b, flat, _ = config_scene(name)
     gpu_ctx.upload(flat)
     kw = dict(n_slices=3, max_depth=12, seed=23)
-    for extra in (0, abi.FLAG_COUNTERS):
+    for extra, wf_extra in ((0, 0), (abi.FLAG_COUNTERS, 0), (0, abi.FLAG_NO_FINISH_KERNEL)):
         one = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_PERSISTENT | extra, **kw))
-        two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT | extra, **kw))
+        two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT | extra | wf_extra, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
         assert one["counters"] == two["counters"]
