@@ -278,6 +278,9 @@ struct rr_context {
     void* wf_mem = nullptr;
     size_t wf_bytes = 0;
     uint32_t* wf_host_count = nullptr;
+    hipStream_t wf_aux = nullptr;                 // the stragglers and the accumulation of a batch run here, beside the next batch
+    hipEvent_t wf_ev_main[2] = {nullptr, nullptr};  // per workspace: the batch's bounce loop is enqueued
+    hipEvent_t wf_ev_aux[2] = {nullptr, nullptr};   // per workspace: the batch is accumulated, the workspace is free
 };
 
 namespace {
@@ -668,21 +671,25 @@ int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t n_sl, ui
 // bounces a batch takes is only known on the device, so the host reads the live-path count back
 // every few bounces and this function returns when the last batch's paths have ended.
 int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, float* sums, unsigned long long* counters, hipStream_t stream) {
-    // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path); the
-    // short low-occupancy tail at the end of a bounce loop is paid once per batch.
+    // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path).  Two workspaces
+    // take turns: the last paths of a batch (whose bounces each last as long as their slowest ray while the
+    // chip idles) and its accumulation run on a second stream beside the next batch's bounce loop.
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 2), static_cast<size_t>(1) << 20);
-    uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(budget / (80u * static_cast<uint64_t>(a.n_slots)), (1ull << 31) / a.n_slots));
+    // per workspace: at most 16 GiB and a quarter of what is free
+    const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
+    const uint64_t most = (1ull << 31) / a.n_slots;
+    uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(budget / (80u * static_cast<uint64_t>(a.n_slots)), most));
+    const bool two = batch < a.spt;  // more than one batch: a second workspace, so that they overlap
     batch = std::min<uint64_t>(batch, std::max(a.spt, 1u));
     const size_t n = static_cast<size_t>(a.n_slots) * batch;
     auto align = [](size_t v) { return (v + 255u) & ~static_cast<size_t>(255u); };
     const size_t off_o = 0, off_d = off_o + align(n * 16), off_t = off_d + align(n * 16), off_h = off_t + align(n * 16),
                  off_q0 = off_h + align(n * 16), off_q1 = off_q0 + align(n * 4), off_ctl = off_q1 + align(n * 4),
-                 need = off_ctl + align(3 * sizeof(WfCtl));
+                 one = off_ctl + align(3 * sizeof(WfCtl)), need = one * (two ? 2u : 1u);
     if (need > ctx->wf_bytes) {
         if (ctx->wf_mem) {
-            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(ctx->wf_mem));
             ctx->wf_mem = nullptr;
             ctx->wf_bytes = 0;
@@ -691,11 +698,26 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
         ctx->wf_bytes = need;
     }
     if (!ctx->wf_host_count) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->wf_host_count), 64, hipHostMallocDefault));
-    char* base = static_cast<char*>(ctx->wf_mem);
-    WfState st{reinterpret_cast<float4*>(base + off_o), reinterpret_cast<float4*>(base + off_d), reinterpret_cast<float4*>(base + off_t),
-               reinterpret_cast<uint4*>(base + off_h)};
-    uint32_t* queue[2] = {reinterpret_cast<uint32_t*>(base + off_q0), reinterpret_cast<uint32_t*>(base + off_q1)};
-    WfCtl* ctl = reinterpret_cast<WfCtl*>(base + off_ctl);
+    if (!ctx->wf_aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->wf_aux, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&ctx->wf_ev_main[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->wf_ev_aux[k], hipEventDisableTiming));
+        }
+    }
+    struct Workspace {
+        WfState st;
+        uint32_t* queue[2];
+        WfCtl* ctl;
+    } ws[2];
+    for (int k = 0; k < 2; ++k) {
+        char* base = static_cast<char*>(ctx->wf_mem) + (two ? k * one : 0);
+        ws[k].st = WfState{reinterpret_cast<float4*>(base + off_o), reinterpret_cast<float4*>(base + off_d),
+                           reinterpret_cast<float4*>(base + off_t), reinterpret_cast<uint4*>(base + off_h)};
+        ws[k].queue[0] = reinterpret_cast<uint32_t*>(base + off_q0);
+        ws[k].queue[1] = reinterpret_cast<uint32_t*>(base + off_q1);
+        ws[k].ctl = reinterpret_cast<WfCtl*>(base + off_ctl);
+    }
 
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     const void* kernel = count ? reinterpret_cast<const void*>(&k_wf_traverse<true>) : reinterpret_cast<const void*>(&k_wf_traverse<false>);
@@ -705,13 +727,24 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     int grid_finish = 0;
     if (int rc = launch_dims(ctx, lds, count ? reinterpret_cast<const void*>(&k_wf_finish<true>) : reinterpret_cast<const void*>(&k_wf_finish<false>), &grid_finish))
         return rc;
+    hipStream_t aux = ctx->wf_aux;
 
-    // The host learns the number of live paths by reading it back (a stream synchronisation) after every bounce
-    // from the fourth on; when few are left, one launch of k_wf_finish runs them to their ends.
+    // The host learns the number of live paths by reading it back (a synchronisation with the caller's stream)
+    // after every bounce from the fourth on; when few are left, one launch of k_wf_finish runs them to their ends.
     constexpr uint32_t POLL_FROM = 3, FINISH_FRACTION = 64, FINISH_MIN = 1u << 16;
-    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
+    uint32_t n_batches = 0;
+    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch), ++n_batches) {
+        const int w = two ? static_cast<int>(n_batches & 1u) : 0;
+        const WfState& st = ws[w].st;
+        uint32_t* const* queue = ws[w].queue;
+        WfCtl* ctl = ws[w].ctl;
         a.s0 = s0;
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        // the workspace is free once the batch that used it last has been accumulated
+        if (n_batches >= (two ? 2u : 1u)) HIP_TRY(hipStreamWaitEvent(stream, ctx->wf_ev_aux[w], 0));
+        uint32_t finish_live = 0;
+        const uint32_t* finish_queue = nullptr;
+        const WfCtl* finish_ctl = nullptr;
         if (a.n_paths != 0) {
             const uint32_t path_blocks = (a.n_paths + 255u) / 256u;
             hipLaunchKernelGGL(k_wf_init, dim3(std::min<uint32_t>(path_blocks, static_cast<uint32_t>(ctx->n_cus) * 32u)), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
@@ -737,21 +770,35 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
                     live = *ctx->wf_host_count;
                     if (live == 0) break;
                     if (live <= std::max(a.n_paths / FINISH_FRACTION, FINISH_MIN) && !(flags & RR_FLAG_NO_FINISH_KERNEL)) {
-                        const uint32_t grid_f = std::min<uint32_t>((live + 255u) / 256u, static_cast<uint32_t>(grid_finish));
-                        if (count)
-                            hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid_f), dim3(256), lds, stream, ctx->sc, a, st, q_out, c_out, ctx->root, counters);
-                        else
-                            hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid_f), dim3(256), lds, stream, ctx->sc, a, st, q_out, c_out, ctx->root, counters);
-                        HIP_TRY(hipGetLastError());
+                        finish_live = live;
+                        finish_queue = q_out;
+                        finish_ctl = c_out;
                         break;
                     }
                 }
             }
         }
-        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
+        // stragglers and accumulation on the second stream, in batch order (render.rs:99 adds samples in order)
+        HIP_TRY(hipEventRecord(ctx->wf_ev_main[w], stream));
+        HIP_TRY(hipStreamWaitEvent(aux, ctx->wf_ev_main[w], 0));
+        if (finish_live != 0) {
+            const uint32_t grid_f = std::min<uint32_t>((finish_live + 255u) / 256u, static_cast<uint32_t>(grid_finish));
+            if (count)
+                hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, ctx->root, counters);
+            else
+                hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, ctx->root, counters);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, aux, a, st, sums);
         HIP_TRY(hipGetLastError());
-        if (a.spt == 0) break;
+        HIP_TRY(hipEventRecord(ctx->wf_ev_aux[w], aux));
+        if (a.spt == 0) {
+            ++n_batches;
+            break;
+        }
     }
+    // the caller's stream goes on after the last accumulations
+    for (uint32_t k = 0; k < std::min(n_batches, two ? 2u : 1u); ++k) HIP_TRY(hipStreamWaitEvent(stream, ctx->wf_ev_aux[two ? k : 0], 0));
     return RR_OK;
 }
 
@@ -801,6 +848,11 @@ int rr_context_destroy(rr_context* ctx) {
     ctx->scene_mem.release();
     if (ctx->wf_mem) (void)hipFree(ctx->wf_mem);
     if (ctx->wf_host_count) (void)hipHostFree(ctx->wf_host_count);
+    if (ctx->wf_aux) (void)hipStreamDestroy(ctx->wf_aux);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->wf_ev_main[k]) (void)hipEventDestroy(ctx->wf_ev_main[k]);
+        if (ctx->wf_ev_aux[k]) (void)hipEventDestroy(ctx->wf_ev_aux[k]);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
