@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -678,7 +679,9 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     // per workspace: at most 16 GiB and a quarter of what is free
     const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
-    const uint64_t most = (1ull << 31) / a.n_slots;
+    size_t cap = budget;
+    if (const char* env = std::getenv("RR_WF_WORKSPACE_BYTES")) cap = std::max<size_t>(1, std::strtoull(env, nullptr, 10));  // for tests
+    const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, std::max<uint64_t>(1, cap / (80u * static_cast<uint64_t>(a.n_slots))));
     uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(budget / (80u * static_cast<uint64_t>(a.n_slots)), most));
     const bool two = batch < a.spt;  // more than one batch: a second workspace, so that they overlap
     batch = std::min<uint64_t>(batch, std::max(a.spt, 1u));

@@ -208,6 +208,21 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         assert one["counters"] == two["counters"]
 
 
+def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch):
+    """Many small batches (the workspace is capped for the test), alternating between the two workspaces, the
+    stragglers and the accumulation of one running beside the bounces of the next: same bits as one lane per
+    pixel summing its samples in order."""
+    b, flat, _ = config_scene("suzanne")
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=2, max_depth=40, seed=31)
+    one = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_PERSISTENT, **kw))
+    monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(80 * 2 * 40 * 32 * 5))  # five samples per slot and batch: 5 batches of 23
+    for extra in (0, abi.FLAG_NO_FINISH_KERNEL):
+        two = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_WAVEFRONT | extra, **kw))
+        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
+        assert one["counters"] == two["counters"]
+
+
 # --------------------------------------------------- size-independent properties
 def test_render_is_deterministic_and_slices_compose(gpu_ctx):
     """Bit-identical reruns; rendering slice ranges separately equals rendering them together; a
