@@ -307,8 +307,9 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
  * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream).  The
  * persistent kernel is enqueued and the call returns without synchronising; the
  * wavefront pipeline launches a pair of kernels per bounce until no path is left,
- * which the host learns by synchronising with the stream every few bounces, so
- * that call returns when the path tracing itself (not the resolve) is complete. */
+ * which the host learns by synchronising with the stream after a bounce; part of
+ * the work runs on a stream of the library's own, ordered against hip_stream by
+ * events, so whatever the caller enqueues on hip_stream afterwards sees the result. */
 int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
                      void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
 
