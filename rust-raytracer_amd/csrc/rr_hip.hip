@@ -373,16 +373,10 @@ struct Walker {
             case RR_TAG_MOVING_SPHERE: {
                 owner_msphere[idx] = owner;
                 const rr_moving_sphere& p = s.moving_spheres[idx];
-                const double r = std::fabs(static_cast<double>(p.radius));
-                // the centre moves linearly in the ray's time (collider.rs:269-271), which the camera draws
-                // from its shutter interval (camera.rs:83): the extreme positions are at the interval's ends
-                for (const float t : {s.camera.shutter_open, s.camera.shutter_close}) {
-                    const double f = (static_cast<double>(t) - p.time0) / (static_cast<double>(p.time1) - p.time0);
-                    double c[3];
-                    for (int a = 0; a < 3; ++a) c[a] = p.center0[a] + f * (static_cast<double>(p.center1[a]) - p.center0[a]);
-                    below.add_point(c[0] - r, c[1] - r, c[2] - r);
-                    below.add_point(c[0] + r, c[1] + r, c[2] + r);
-                }
+                // the centre moves with the ray's time (collider.rs:269-271), which a caller of rr_primary_hits is
+                // free to choose: a BVH node over a moving sphere has no bounds to cull with
+                below.add_point(p.center0[0], p.center0[1], p.center0[2]);
+                below.bounded = false;
                 return mat_ok(p.material);
             }
             case RR_TAG_RECT: {
