@@ -394,10 +394,41 @@ struct Walker {
             case RR_TAG_TRIANGLE: {
                 owner_tri[idx] = owner;
                 const rr_triangle& p = s.triangles[idx];
-                below.add_point(p.p0[0], p.p0[1], p.p0[2]);
-                below.add_point(p.p1[0], p.p1[1], p.p1[2]);
-                below.add_point(p.p2[0], p.p2[1], p.p2[2]);
                 below.has_tri = true;
+                // Where can a ray be accepted?  intersect_triangle (collider.rs:627-661) takes the point of the ray on
+                // the plane (normal, p0) and accepts it if three products n . (edge x (point - corner)) are >= 0 in f32.
+                // Each product is |edge| times the distance to the edge's line, known to about 16 ulps of
+                // |edge| * |point - corner|: points up to delta = 16 * 2^-24 * L * (L / h) outside the triangle pass,
+                // L the longest edge and h the smallest altitude (a sliver's tip moves out by 1 / sin of its angle).
+                // The bounds grow by delta; a triangle without area, with a corner or a stored normal that is not
+                // finite, or with a stored normal that is not its unit normal accepts points that have nothing to do
+                // with its corners (every comparison with NaN is false) and has no bounds at all.
+                const double q[3][3] = {{p.p0[0], p.p0[1], p.p0[2]}, {p.p1[0], p.p1[1], p.p1[2]}, {p.p2[0], p.p2[1], p.p2[2]}};
+                double e[3][3], len[3], cr[3];
+                for (int k = 0; k < 3; ++k) {
+                    for (int c = 0; c < 3; ++c) e[k][c] = q[(k + 1) % 3][c] - q[k][c];
+                    len[k] = std::sqrt(e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
+                }
+                cr[0] = e[0][1] * -e[2][2] - e[0][2] * -e[2][1];
+                cr[1] = e[0][2] * -e[2][0] - e[0][0] * -e[2][2];
+                cr[2] = e[0][0] * -e[2][1] - e[0][1] * -e[2][0];
+                const double area2 = std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);  // twice the area
+                const double longest = std::max({len[0], len[1], len[2]});
+                bool sound = area2 > 0.0 && area2 == area2 && longest < 1e30;
+                double delta = 0.0;
+                if (sound) {
+                    double off = 0.0;  // the stored normal against +- the unit normal of the corners
+                    double dotn = 0.0;
+                    for (int c = 0; c < 3; ++c) dotn += p.normal[c] * cr[c] / area2;
+                    for (int c = 0; c < 3; ++c) off = std::max(off, std::fabs(p.normal[c] - (dotn < 0 ? -1.0 : 1.0) * cr[c] / area2));
+                    sound = off == off && off <= 1e-3;
+                    delta = 16.0 * 5.9604644775390625e-8 * longest * (longest / (area2 / longest));
+                }
+                for (int k = 0; k < 3; ++k) {
+                    below.add_point(q[k][0] - delta, q[k][1] - delta, q[k][2] - delta);
+                    below.add_point(q[k][0] + delta, q[k][1] + delta, q[k][2] + delta);
+                }
+                if (!sound) below.bounded = false;
                 return mat_ok(p.material);
             }
             case RR_TAG_CUBOID: {

@@ -99,6 +99,72 @@ def test_culling_and_visit_skipping_never_change_a_hit(gpu_ctx, name, kw):
     compare_hits(got, want, exact_t=(name != "final"))
 
 
+def _random_scene(seed):
+    """A scene thrown together from every kind of geometry, in nested BVHs, instances and lists, with the
+    awkward cases in: tiny and huge and negative radii, degenerate triangles, flat boxes, a medium in a BVH,
+    a BVH inside a rotated, translated BVH, a moving sphere in a BVH."""
+    rng = np.random.default_rng(seed)
+    b = host.SceneBuilder(seed)
+    mats = [b.lambertian(b.solid_color((0.7, 0.6, 0.5))), b.glossy((0.8, 0.8, 0.9), 0.3), b.dielectric(1.5),
+            b.emissive((4, 4, 4))]
+
+    def mat():
+        return mats[int(rng.integers(0, len(mats)))]
+
+    def prim(scale):
+        c = rng.uniform(-scale, scale, 3)
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            return b.sphere(c, float(10.0 ** rng.uniform(-3, np.log10(scale))), mat())
+        if k == 1:
+            return b.sphere(c, -float(rng.uniform(0.1, 0.3) * scale), mat())  # hollow-glass style negative radius
+        if k == 2:
+            e = rng.uniform(0.01, 0.5, 2) * scale
+            f = [b.xyrect, b.xzrect, b.yzrect][int(rng.integers(0, 3))]
+            return f(c[0], c[0] + e[0], c[1], c[1] + e[1], float(c[2]), mat())
+        if k == 3:
+            e = rng.uniform(0.0, 0.4, 3) * scale  # an edge can be zero: a flat box
+            return b.cuboid(c, c + e, mat())
+        if k == 4:
+            p = c + rng.normal(size=(3, 3)) * scale * float(10.0 ** rng.uniform(-3, -0.3))
+            return b.triangle(p[0], p[1], p[2], mat())
+        if k == 5:
+            return b.triangle(c, c, c + 1.0, mat())  # two equal corners
+        return b.moving_sphere(c, c + rng.normal(size=3), 0.0, 1.0, float(rng.uniform(0.05, 0.3) * scale), mat())
+
+    def group(n, scale):
+        items = [prim(scale) for _ in range(n)]
+        if rng.random() < 0.3:
+            items.append(b.constant_medium(b.sphere(rng.uniform(-scale, scale, 3), float(0.3 * scale), mats[0]), 0.5, (1, 1, 1)))
+        return b.bvh_node(items)
+
+    inner = group(int(rng.integers(3, 40)), 5.0)
+    nested = b.instance_translation(b.instance_rotation(inner, int(rng.integers(0, 3)), float(rng.uniform(-170, 170))), rng.uniform(-20, 20, 3))
+    b.add(b.bvh_node([nested] + [prim(30.0) for _ in range(int(rng.integers(2, 60)))]))
+    b.add(group(int(rng.integers(1, 200)), 50.0))
+    b.add(b.collider_list([prim(10.0), b.instance_translation(group(int(rng.integers(2, 30)), 3.0), rng.uniform(-40, 40, 3))]))
+    b.add(b.sphere((0, -1000, 0), 990.0, mats[0]))  # a huge sphere next to the small ones
+    b.set_lights(b.xzrect(-5, 5, -5, 5, 60.0, mats[3]))
+    b.set_camera((0, 20, -120), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+    b.set_background((0.5, 0.6, 0.9))
+    return b, b.flatten()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_production_traversal_on_random_scenes(gpu_ctx, seed):
+    """Culling classes, visit skipping, one-word frames and the scene program against the recursive oracle on
+    scenes nobody tuned them for: identical primitive, t, point and normal for 60 000 rays each."""
+    b, flat = _random_scene(seed)
+    info = gpu_ctx.upload(flat)
+    rays = _stress_rays(flat, 60_000, seed=100 + seed)
+    rays[:, :3] *= 0.3  # most origins inside the cloud of objects
+    got = gpu_ctx.primary_hits(rays, seed=4)
+    want = O.primary_hits(flat, rays, seed=4)
+    compare_hits(got, want, exact_t=(flat.n_media == 0))
+    assert (want["prim_id"] >= 0).mean() > 0.2
+    assert sum(info["bvh_nodes_by_class"]) > 0
+
+
 # ------------------------------------------------------------ whole renders
 def render_both(ctx, flat, p, n_threads=16):
     ctx.upload(flat)
