@@ -165,6 +165,22 @@ def test_production_traversal_on_random_scenes(gpu_ctx, seed):
     assert sum(info["bvh_nodes_by_class"]) > 0
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_renders_of_random_scenes_agree_between_all_kernel_forms(gpu_ctx, seed):
+    """Whole paths (bounce rays start on surfaces, inside media, at grazing angles) through randomly assembled
+    scenes: production kernels, reference-order kernels and the persistent kernel produce the same bits."""
+    b, flat = _random_scene(40 + seed)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=2, max_depth=25, seed=3)
+    base = gpu_ctx.render(device.make_params(48, 40, 8, **kw))
+    for flags in (abi.FLAG_COUNTERS, abi.FLAG_PERSISTENT, abi.FLAG_PERSISTENT | abi.FLAG_COUNTERS, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL):
+        other = gpu_ctx.render(device.make_params(48, 40, 8, flags=flags, **kw))
+        assert np.array_equal(base["slice_sums"], other["slice_sums"], equal_nan=True), flags
+    want = O.render(flat, O.make_params(48, 40, 8, **kw), n_threads=8)
+    both = ~np.isnan(base["slice_sums"]) & ~np.isnan(want["slice_sums"])
+    assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.95
+
+
 # ------------------------------------------------------------ whole renders
 def render_both(ctx, flat, p, n_threads=16):
     ctx.upload(flat)
