@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3    # MI355X peak vector f32 (spec)
 
 WORKLOADS = {
-    # name: (scene, width, height, spp, depth)  — BASELINE.json configs[1..4]
+    # name: (scene, width, height, spp, depth): the benchmark configurations
     "cornell": ("cornell", 600, 600, 1000, 200),
     "suzanne": ("suzanne", 800, 800, 1000, 100),
     "final": ("final", 800, 800, 10000, 50),

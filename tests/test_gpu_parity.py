@@ -328,7 +328,7 @@ def test_render_is_deterministic_and_slices_compose(gpu_ctx):
 
 
 def test_full_size_cornell_configuration(gpu_ctx):
-    """BASELINE configuration 2 at full size (600x600, 1000 spp, depth 200): every sample is traced,
+    """The headline benchmark configuration at full size (Cornell box, 600x600, 1000 spp, depth 200): every sample is traced,
     nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""
     b, flat, _ = config_scene("cornell")
     gpu_ctx.upload(flat)
