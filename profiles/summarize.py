@@ -7,7 +7,7 @@
   <tag>_pmc_traffic.json              HBM bytes per sample and workload (read by bench.py for roofline.traffic)
 
 Only the kernels of the timed step count: bench.py's instrumented pass afterwards is cut off at the first dispatch of a
-counting kernel (k_render<true> / k_wf_traverse<true>).
+counting kernel (k_render<true> / k_wf_traverse<true> / k_wf_finish<true>).
 
 usage: python profiles/summarize.py <tag> <workload>
 """
@@ -30,8 +30,8 @@ def short(name):
         return "k_render<false>"
     if "k_render<true" in name:
         return "k_render<true>"
-    for k in ("k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_shade", "k_wf_init",
-              "k_wf_accumulate", "k_resolve", "k_cast_u8"):
+    for k in ("k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_finish<false>", "k_wf_finish<true>", "k_wf_shade",
+              "k_wf_init", "k_wf_accumulate", "k_resolve", "k_cast_u8"):
         if k in name:
             return k
     return None
@@ -44,7 +44,7 @@ def newest(pattern):
 
 
 def counting(name):
-    return "k_render<true" in name or "k_wf_traverse<true>" in name
+    return "k_render<true" in name or "k_wf_traverse<true>" in name or "k_wf_finish<true>" in name
 
 
 def last_json_line(path):
@@ -70,6 +70,8 @@ if trace:
     rows = rows[:cut]
     steps = bench["steps"] + bench["warmup"]
     casts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_cast_u8"]
+    if casts:
+        rows = rows[:casts[-1] + 1]  # a timed step ends with its cast: what follows belongs to the instrumented pass
     if len(casts) == steps and bench["warmup"] > 0:
         rows = rows[casts[bench["warmup"] - 1] + 1:]  # drop the warm-up steps
     per = collections.OrderedDict()
