@@ -65,6 +65,11 @@ int rrh_bvh_node_explicit(rrh_builder* b, int left, int right, uint32_t axis, in
 int rrh_collider_list(rrh_builder* b, const int* geometries, uint32_t n);
 int rrh_triangle(rrh_builder* b, const float p0[3], const float p1[3], const float p2[3], int material);
 int rrh_load_obj(rrh_builder* b, const char* path, float scale, int material);
+/* Not the reference's reader (collider.rs:227-267 takes "vn" lines for vertices, reads three corners of
+ * every face and no negative indices): only "v" lines are vertices, negative indices count back from the
+ * vertex read last, faces of more than three corners become fans.  Same triangles as rrh_load_obj on
+ * files the reference reads correctly.                                                                */
+int rrh_load_obj_hardened(rrh_builder* b, const char* path, float scale, int material);
 
 /* bounding_box(time_0, time_1) of a geometry (collider.rs:698-713): returns 1 and fills
  * out[6] = min xyz, max xyz; 0 when the geometry has no box.                        */

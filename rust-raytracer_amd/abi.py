@@ -202,6 +202,7 @@ HOST_PROTOTYPES = {
     "rrh_collider_list": (C.c_int, [vp, P(C.c_int), u32]),
     "rrh_triangle": (C.c_int, [vp, f3, f3, f3, C.c_int]),
     "rrh_load_obj": (C.c_int, [vp, C.c_char_p, f32, C.c_int]),
+    "rrh_load_obj_hardened": (C.c_int, [vp, C.c_char_p, f32, C.c_int]),
     "rrh_bounding_box": (C.c_int, [vp, C.c_int, f32, f32, f3]),
     "rrh_scene_add": (C.c_int, [vp, C.c_int]),
     "rrh_set_lights": (C.c_int, [vp, C.c_int]),

@@ -150,8 +150,11 @@ class SceneBuilder:
     def triangle(self, p0, p1, p2, material):
         return self._h(self._l.rrh_triangle(self._b, abi.vec3(p0), abi.vec3(p1), abi.vec3(p2), material))
 
-    def load_obj(self, path, scale, material):
-        return self._h(self._l.rrh_load_obj(self._b, path.encode(), scale, material))
+    def load_obj(self, path, scale, material, hardened=False):
+        """Geometry::load_obj (collider.rs:227-267).  hardened=True is not the reference's reader: "vn" lines are not
+        vertices, indices may be negative, polygons become fans."""
+        f = self._l.rrh_load_obj_hardened if hardened else self._l.rrh_load_obj
+        return self._h(f(self._b, path.encode(), scale, material))
 
     def bounding_box(self, geometry, time_0=0.0, time_1=1.0):
         out = (C.c_float * 6)()

@@ -174,6 +174,9 @@ int rrh_triangle(rrh_builder* b, const float p0[3], const float p1[3], const flo
 int rrh_load_obj(rrh_builder* b, const char* path, float scale, int m) {
     return guarded([&] { return push_geom(b, Geometry::load_obj(path, scale, mat(b, m), b->rng)); });
 }
+int rrh_load_obj_hardened(rrh_builder* b, const char* path, float scale, int m) {
+    return guarded([&] { return push_geom(b, Geometry::load_obj(path, scale, mat(b, m), b->rng, true)); });
+}
 
 int rrh_bounding_box(rrh_builder* b, int g, float t0, float t1, float out[6]) {
     return guarded([&] {

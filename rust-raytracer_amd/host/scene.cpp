@@ -396,7 +396,13 @@ GeometryPtr Geometry::bvh_node_explicit(GeometryPtr left, GeometryPtr right, uin
 // a token starting with "f" reads exactly three 1-based indices, taking the part
 // before the first '/' when the first index has slashes.  Everything becomes one
 // BVH over the triangles with shutter [0,1].
-GeometryPtr Geometry::load_obj(const std::string& path, float scale, Material m, Rng& rng) {
+//
+// hardened = true is NOT the reference's reader: only "v" lines are vertices ("vn",
+// "vp" and the rest are skipped), an index may be negative (relative to the vertices
+// read so far), and a face of n > 3 corners becomes the fan (0, i, i+1).  Files the
+// reference reads correctly (triangles, positive indices, no "vn" lines before the
+// faces that use later vertices) give the same triangles in the same order either way.
+GeometryPtr Geometry::load_obj(const std::string& path, float scale, Material m, Rng& rng, bool hardened) {
     std::ifstream in(path);
     if (!in) throw std::runtime_error("load_obj: cannot open " + path);
     std::vector<Vec3> vertices;
@@ -408,18 +414,36 @@ GeometryPtr Geometry::load_obj(const std::string& path, float scale, Material m,
         if (!(ss >> action)) continue;
         if (action.rfind("vt", 0) == 0) {
             continue;
-        } else if (action.rfind("v", 0) == 0) {
+        } else if (hardened ? action == "v" : action.rfind("v", 0) == 0) {
             float a, b, c;
             if (!(ss >> a >> b >> c)) throw std::runtime_error("load_obj: bad vertex line in " + path);
             vertices.push_back(Vec3(a * scale, b * scale, c * scale));
-        } else if (action.rfind("f", 0) == 0) {
-            std::array<size_t, 3> idx{};
-            for (int i = 0; i < 3; ++i) {
-                std::string tok;
-                if (!(ss >> tok)) throw std::runtime_error("load_obj: face with fewer than 3 indices in " + path);
-                idx[i] = static_cast<size_t>(std::stoull(tok.substr(0, tok.find('/'))));
+        } else if (hardened ? action == "f" : action.rfind("f", 0) == 0) {
+            if (!hardened) {
+                std::array<size_t, 3> idx{};
+                for (int i = 0; i < 3; ++i) {
+                    std::string tok;
+                    if (!(ss >> tok)) throw std::runtime_error("load_obj: face with fewer than 3 indices in " + path);
+                    idx[i] = static_cast<size_t>(std::stoull(tok.substr(0, tok.find('/'))));
+                }
+                faces.push_back(idx);
+                continue;
             }
-            faces.push_back(idx);
+            std::vector<size_t> corners;
+            std::string tok;
+            while (ss >> tok) {
+                long long i = 0;
+                try {
+                    i = std::stoll(tok.substr(0, tok.find('/')));
+                } catch (const std::exception&) {
+                    throw std::runtime_error("load_obj: bad face index '" + tok + "' in " + path);
+                }
+                if (i < 0) i += static_cast<long long>(vertices.size()) + 1;  // -1 = the vertex read last
+                if (i < 1 || i > static_cast<long long>(vertices.size())) throw std::runtime_error("load_obj: face index out of range in " + path);
+                corners.push_back(static_cast<size_t>(i));
+            }
+            if (corners.size() < 3) throw std::runtime_error("load_obj: face with fewer than 3 indices in " + path);
+            for (size_t i = 1; i + 1 < corners.size(); ++i) faces.push_back({corners[0], corners[i], corners[i + 1]});
         }
     }
     std::vector<GeometryPtr> tris;

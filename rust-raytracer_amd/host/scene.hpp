@@ -221,7 +221,7 @@ class Geometry {
                                          std::optional<AABB> box);
     static GeometryPtr collider_list(std::vector<GeometryPtr> colliders);
     static GeometryPtr triangle(Point3 p0, Point3 p1, Point3 p2, Material m);
-    static GeometryPtr load_obj(const std::string& path, float scale, Material m, Rng& rng);
+    static GeometryPtr load_obj(const std::string& path, float scale, Material m, Rng& rng, bool hardened = false);
 
     std::optional<AABB> bounding_box(float time_0, float time_1) const;  // collider.rs:698-713
 };

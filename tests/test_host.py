@@ -213,6 +213,38 @@ def test_obj_reader_quirks(built, tmp_path):
         b.load_obj(str(bad), 1.0, m)
 
 
+def test_obj_reader_hardened_option(built, tmp_path):
+    """The labelled non-reference reader: 'vn' is not a vertex, quads fan out, negative indices count back."""
+    p = tmp_path / "q.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nvn 0 0 1\nv 1 1 0\nv 0 1 0\nf 1//1 2//1 3//1 4//1\nv 0 0 1\nf -1 -5 -4\nvp 1 2 3\n")
+    b = host.SceneBuilder(1)
+    m = b.lambertian(b.solid_color((1, 1, 1)))
+    b.add(b.load_obj(str(p), 1.0, m, hardened=True))
+    flat = b.flatten()
+    assert flat.n_triangles == 3
+    tris = {tuple(map(tuple, (t.p0, t.p1, t.p2))) for t in (flat.triangles[i] for i in range(3))}
+    assert tris == {((0, 0, 0), (1, 0, 0), (1, 1, 0)), ((0, 0, 0), (1, 1, 0), (0, 1, 0)), ((0, 0, 1), (0, 0, 0), (1, 0, 0))}
+    for text, msg in (("v 0 0 0\nv 1 0 0\nf 1 2\n", "fewer than 3"), ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -4\n", "out of range"),
+                      ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 x 3\n", "bad face index")):
+        bad = tmp_path / "bad.obj"
+        bad.write_text(text)
+        with pytest.raises(host.HostError, match=msg):
+            b.load_obj(str(bad), 1.0, m, hardened=True)
+    # a file the reference reads correctly gives the same triangles, in the same order, either way
+    import os
+    obj = os.path.join(host.ASSETS, "suzanne.obj")
+    assert os.path.exists(obj)
+    if True:
+        fl = []
+        for hardened in (False, True):
+            bb = host.SceneBuilder(7)
+            mm = bb.lambertian(bb.solid_color((1, 1, 1)))
+            bb.add(bb.load_obj(obj, 80.0, mm, hardened=hardened))
+            f = bb.flatten()
+            fl.append([(tuple(f.triangles[i].p0), tuple(f.triangles[i].p1), tuple(f.triangles[i].p2)) for i in range(f.n_triangles)])
+        assert fl[0] == fl[1] and len(fl[0]) == 968
+
+
 def test_suzanne_mesh_and_pedestal_scene(built):
     b, flat, d = host.build_config_scene("suzanne")
     assert flat.n_triangles == 968 and flat.n_bvh_nodes == 1023
