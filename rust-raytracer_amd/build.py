@@ -1,4 +1,4 @@
-"""In-tree builds: librr_hip.so (hipcc, gfx950), librr_host.so (g++), oracle/librr_oracle.so (make).
+"""In-tree builds: librr_hip.so (hipcc, gfx950), librr_host.so (g++), oracle/librr_oracle.so (make), examples/render_scene (gcc).
 
 hipcc cross-compiles without a GPU, so all three build on a CPU-only box.  A library is
 rebuilt when it is older than any of its sources.
@@ -61,5 +61,16 @@ def build_oracle(force=False):
     return os.path.join(d, "librr_oracle.so")
 
 
+def build_example(force=False):
+    """examples/render_scene: the two C ABIs used from plain C (gcc -std=c99), linked against the in-tree libraries."""
+    d = os.path.join(abi.REPO_DIR, "examples")
+    src = os.path.join(d, "render_scene.c")
+    exe = os.path.join(d, "render_scene")
+    if force or _stale(exe, [src, abi.HIP_LIB, abi.HOST_LIB] + _headers()):
+        _run([os.environ.get("CC", "gcc"), "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-I", INCLUDE, src, "-L", abi.PKG_DIR,
+              "-lrr_hip", "-lrr_host", "-Wl,-rpath,$ORIGIN/../" + os.path.basename(abi.PKG_DIR), "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", exe])
+    return exe
+
+
 def build_all(force=False):
-    return [build_hip(force), build_host(force), build_oracle(force)]
+    return [build_hip(force), build_host(force), build_oracle(force), build_example(force)]
