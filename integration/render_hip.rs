@@ -1,0 +1,248 @@
+// render_hip — render_multi (src/render.rs:128) on an MI355X.
+//
+// To be added to the reference as src/render_hip.rs, next to render.rs (`#[path = "render_hip.rs"] mod
+// render_hip;` in main.rs, `rr-hip-sys = { path = ".../integration/rr-hip-sys" }` in Cargo.toml), and
+// called from main.rs:548 in place of render_multi: same arguments, same return type.
+//
+// NOT COMPILED: no Rust toolchain exists where this was written.  It follows the rules the device library
+// documents for its input (include/rr_hip.h) and that the C++ flattener of this repository
+// (rust-raytracer_amd/host/flatten.cpp) implements and tests; read it as the maintainer's starting point.
+// Two things the reference has to grant first: `Perlin`'s fields are private (perlin.rs:6-11) — make them
+// pub(crate) — and `image::DynamicImage::to_rgb8()` is used to read the atlas (texture.rs:9-23).
+use std::collections::HashMap;
+use std::ffi::CStr;
+use std::ptr::{null, null_mut};
+
+use image::{ImageBuffer, Rgb as ImgRgb};
+use rr_hip_sys::*;
+
+use crate::*; // Geometry, GeometryType, Material, MaterialType, Texture, TextureType, Camera, Rgb, Axis, SceneColliders
+
+#[derive(Default)]
+struct Flattener {
+    spheres: Vec<rr_sphere>,
+    moving_spheres: Vec<rr_moving_sphere>,
+    rects: Vec<rr_rect>,
+    triangles: Vec<rr_triangle>,
+    cuboids: Vec<rr_cuboid>,
+    media: Vec<rr_medium>,
+    instances: Vec<rr_instance>,
+    bvh_nodes: Vec<rr_bvh_node>,
+    lists: Vec<rr_list>,
+    child_refs: Vec<u32>,
+    materials: Vec<rr_material>,
+    textures: Vec<rr_texture>,
+    perlin: Vec<rr_perlin>,
+    material_ids: HashMap<Vec<u32>, u32>, // one table entry per distinct value (keyed by bit patterns)
+    texture_ids: HashMap<Vec<u32>, u32>,
+    next_prim: u32, // primitive ids: depth-first order of the tree
+}
+
+fn v3(v: Vec3) -> [f32; 3] { [v.x, v.y, v.z] }
+
+impl Flattener {
+    fn prim(&mut self) -> u32 { self.next_prim += 1; self.next_prim - 1 }
+
+    fn texture(&mut self, t: &Texture) -> u32 {
+        let zero = [0.0f32; 3];
+        let (rec, key) = match &t.texture_type {
+            TextureType::SolidColor(c) => (
+                rr_texture { type_: RR_TEX_SOLID, color0: v3(*c), color1: zero, index: 0, scale: 0.0, depth: 0 },
+                vec![RR_TEX_SOLID, c.x.to_bits(), c.y.to_bits(), c.z.to_bits()]),
+            TextureType::Checkered(odd, even) => (
+                rr_texture { type_: RR_TEX_CHECKERED, color0: v3(*odd), color1: v3(*even), index: 0, scale: 0.0, depth: 0 },
+                vec![RR_TEX_CHECKERED, odd.x.to_bits(), odd.y.to_bits(), odd.z.to_bits(), even.x.to_bits(), even.y.to_bits(), even.z.to_bits()]),
+            TextureType::NoiseTexture(p, scale, depth) => {
+                // every Texture::noise owns its own tables (texture.rs:52-56): one rr_perlin per distinct table
+                let mut rec = rr_perlin { ranvec: [[0.0; 3]; 256], perm_x: [0; 256], perm_y: [0; 256], perm_z: [0; 256] };
+                let mut key = vec![RR_TEX_NOISE, scale.to_bits(), *depth as u32];
+                for i in 0..256 {
+                    rec.ranvec[i] = v3(p.rand_vec[i]);
+                    rec.perm_x[i] = p.perm_x[i] as u8; // values are 0..255 (perlin.rs:31-46)
+                    rec.perm_y[i] = p.perm_y[i] as u8;
+                    rec.perm_z[i] = p.perm_z[i] as u8;
+                    key.extend([rec.ranvec[i][0].to_bits(), rec.perm_x[i] as u32, rec.perm_y[i] as u32, rec.perm_z[i] as u32]);
+                }
+                if let Some(&id) = self.texture_ids.get(&key) { return id; }
+                self.perlin.push(rec);
+                (rr_texture { type_: RR_TEX_NOISE, color0: zero, color1: zero, index: self.perlin.len() as u32 - 1, scale: *scale, depth: *depth as u32 }, key)
+            }
+            TextureType::ImageTexture(_bytes_per_pixel, _w, _h, idx) => (
+                rr_texture { type_: RR_TEX_IMAGE, color0: zero, color1: zero, index: *idx as u32, scale: 0.0, depth: 0 },
+                vec![RR_TEX_IMAGE, *idx as u32]),
+        };
+        if let Some(&id) = self.texture_ids.get(&key) { return id; }
+        self.textures.push(rec);
+        let id = self.textures.len() as u32 - 1;
+        self.texture_ids.insert(key, id);
+        id
+    }
+
+    fn material(&mut self, m: &Material) -> u32 {
+        let zero = [0.0f32; 3];
+        let rec = match &m.mat_type {
+            MaterialType::Lambertian(t) => rr_material { type_: RR_MAT_LAMBERTIAN, texture: self.texture(t), color: zero, param: 0.0 },
+            MaterialType::Glossy(c, fuzz) => rr_material { type_: RR_MAT_GLOSSY, texture: 0, color: v3(*c), param: *fuzz },
+            MaterialType::Dielectric(ior) => rr_material { type_: RR_MAT_DIELECTRIC, texture: 0, color: zero, param: *ior },
+            MaterialType::Isotropic(t) => rr_material { type_: RR_MAT_ISOTROPIC, texture: self.texture(t), color: zero, param: 0.0 },
+            MaterialType::Emissive(t) => rr_material { type_: RR_MAT_EMISSIVE, texture: self.texture(t), color: zero, param: 0.0 },
+        };
+        let key = vec![rec.type_, rec.texture, rec.color[0].to_bits(), rec.color[1].to_bits(), rec.color[2].to_bits(), rec.param.to_bits()];
+        if let Some(&id) = self.material_ids.get(&key) { return id; }
+        self.materials.push(rec);
+        let id = self.materials.len() as u32 - 1;
+        self.material_ids.insert(key, id);
+        id
+    }
+
+    fn rect(&mut self, axis: u32, f: (f32, f32, f32, f32, f32), material: u32) -> u32 {
+        let prim_id = self.prim();
+        self.rects.push(rr_rect { a0: f.0, a1: f.1, b0: f.2, b1: f.3, k: f.4, axis, material, prim_id });
+        rr_ref(RR_TAG_RECT, self.rects.len() as u32 - 1)
+    }
+
+    fn list(&mut self, children: Vec<u32>) -> u32 {
+        self.lists.push(rr_list { first_child: self.child_refs.len() as u32, n_children: children.len() as u32 });
+        self.child_refs.extend(children);
+        rr_ref(RR_TAG_LIST, self.lists.len() as u32 - 1)
+    }
+
+    /// One record per node, appended to the array of its kind; returns tag << 28 | index.  The tree is kept
+    /// exactly as built: results depend on visit order (collider.rs:555-561, :627).
+    fn geometry(&mut self, g: &Geometry) -> u32 {
+        let material = self.material(&g.material);
+        match &g.geometry_type {
+            GeometryType::Sphere(c, r) => {
+                let prim_id = self.prim();
+                self.spheres.push(rr_sphere { center: v3(*c), radius: *r, material, prim_id });
+                rr_ref(RR_TAG_SPHERE, self.spheres.len() as u32 - 1)
+            }
+            GeometryType::MovingSphere(c0, c1, t0, t1, r) => {
+                let prim_id = self.prim();
+                self.moving_spheres.push(rr_moving_sphere { center0: v3(*c0), center1: v3(*c1), time0: *t0, time1: *t1, radius: *r, material, prim_id });
+                rr_ref(RR_TAG_MOVING_SPHERE, self.moving_spheres.len() as u32 - 1)
+            }
+            // fields in the enum's order; YZRect's were reordered by its constructor (collider.rs:80-84)
+            GeometryType::XYRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_XY, (*a0, *a1, *b0, *b1, *k), material),
+            GeometryType::XZRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_XZ, (*a0, *a1, *b0, *b1, *k), material),
+            GeometryType::YZRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_YZ, (*a0, *a1, *b0, *b1, *k), material),
+            GeometryType::Cuboid(_p0, _p1, sides) => {
+                // the six sides in constructor order (collider.rs:88-95), consecutive in `rects`
+                let first_rect = self.rects.len() as u32;
+                for s in &sides.objects { self.geometry(s); }
+                assert_eq!(self.rects.len() as u32, first_rect + 6);
+                self.cuboids.push(rr_cuboid { first_rect });
+                rr_ref(RR_TAG_CUBOID, self.cuboids.len() as u32 - 1)
+            }
+            GeometryType::ConstantMedium(boundary, neg_inv_density) => {
+                let prim_id = self.prim(); // numbered before what is inside it (pre-order)
+                let b = self.geometry(boundary);
+                self.media.push(rr_medium { boundary: b, neg_inv_density: *neg_inv_density, material, prim_id });
+                rr_ref(RR_TAG_MEDIUM, self.media.len() as u32 - 1)
+            }
+            GeometryType::TranslateInstance(child, d) => {
+                let c = self.geometry(child);
+                self.instances.push(rr_instance { kind: RR_INST_TRANSLATE, child: c, v: v3(*d) });
+                rr_ref(RR_TAG_INSTANCE, self.instances.len() as u32 - 1)
+            }
+            GeometryType::YRotationInstance(child, axis, _angle, sin, cos, _has_box, _aabb) => {
+                let c = self.geometry(child);
+                let kind = match axis { Axis::X => RR_INST_ROTATE_X, Axis::Y => RR_INST_ROTATE_Y, Axis::Z => RR_INST_ROTATE_Z };
+                self.instances.push(rr_instance { kind, child: c, v: [*sin, *cos, 0.0] });
+                rr_ref(RR_TAG_INSTANCE, self.instances.len() as u32 - 1)
+            }
+            GeometryType::BVHNode(left, right, aabb, axis) => {
+                // a span-1 node holds two clones of one primitive (collider.rs:180-182): flatten it once.
+                // Box<Geometry> has no identity, so "same primitive" is decided by the builder's span; a
+                // maintainer can carry that as a flag, or compare the two children's fields as done here.
+                let l = self.geometry(left);
+                let r = if same_leaf(left, right) { l } else { self.geometry(right) };
+                let (bmin, bmax, has_box) = match aabb { Some(b) => (v3(b.minimum), v3(b.maximum), 1), None => ([0.0; 3], [0.0; 3], 0) };
+                self.bvh_nodes.push(rr_bvh_node { bmin, bmax, left: l, right: r, axis: *axis as u32, has_box });
+                rr_ref(RR_TAG_BVH, self.bvh_nodes.len() as u32 - 1)
+            }
+            GeometryType::ColliderList(v) => {
+                let children: Vec<u32> = v.iter().map(|c| self.geometry(c)).collect();
+                self.list(children)
+            }
+            GeometryType::Triangle(p0, p1, p2, n) => {
+                let prim_id = self.prim();
+                self.triangles.push(rr_triangle { p0: v3(*p0), p1: v3(*p1), p2: v3(*p2), normal: v3(*n), material, prim_id });
+                rr_ref(RR_TAG_TRIANGLE, self.triangles.len() as u32 - 1)
+            }
+        }
+    }
+}
+
+/// Two leaves with bit-identical fields: the two clones a span-1 BVH node holds (collider.rs:180-182).
+fn same_leaf(a: &Geometry, b: &Geometry) -> bool {
+    let bits = |v: &Vec3| [v.x.to_bits(), v.y.to_bits(), v.z.to_bits()];
+    match (&a.geometry_type, &b.geometry_type) {
+        (GeometryType::Sphere(c0, r0), GeometryType::Sphere(c1, r1)) => bits(c0) == bits(c1) && r0.to_bits() == r1.to_bits(),
+        (GeometryType::Triangle(a0, a1, a2, _), GeometryType::Triangle(b0, b1, b2, _)) => bits(a0) == bits(b0) && bits(a1) == bits(b1) && bits(a2) == bits(b2),
+        (GeometryType::MovingSphere(a0, a1, ..), GeometryType::MovingSphere(b0, b1, ..)) => bits(a0) == bits(b0) && bits(a1) == bits(b1),
+        _ => false, // other kinds under a span-1 node: flattened twice, which renders the same image (the second visit repeats the first)
+    }
+}
+
+fn check(rc: i32) {
+    if rc != RR_OK {
+        let msg = unsafe { CStr::from_ptr(rr_last_error()) }.to_string_lossy().into_owned();
+        panic!("rr_hip: {msg} ({rc})"); // the reference reports errors by panicking (unwrap), so does this
+    }
+}
+
+pub fn render_hip(scene: SceneColliders, lights: Geometry, cam: Camera, background: Rgb, max_depth: usize, samples_per_pixel: usize,
+                  img_width: u32, img_height: u32) -> ImageBuffer<ImgRgb<u8>, Vec<u8>> {
+    let mut f = Flattener::default();
+    let top: Vec<u32> = scene.objects.iter().map(|g| f.geometry(g)).collect(); // depth-first, in order
+    let root = f.list(top);
+
+    // images: the atlas' pixels as RGB8 rows, top-down, concatenated
+    let mut images = Vec::new();
+    let mut image_bytes: Vec<u8> = Vec::new();
+    for im in scene.atlas.lock().unwrap().images.iter() {
+        let rgb = im.to_rgb8();
+        images.push(rr_image { width: rgb.width(), height: rgb.height(), offset: image_bytes.len() as u64 });
+        image_bytes.extend_from_slice(rgb.as_raw());
+    }
+
+    // lights: a bare XZRect is sampled; anything else has pdf 0 and direction (1,0,0) (collider.rs:714-725)
+    let light = match &lights.geometry_type {
+        GeometryType::XZRect(x0, x1, z0, z1, k) => rr_light { is_xzrect: 1, x0: *x0, x1: *x1, z0: *z0, z1: *z1, k: *k },
+        _ => rr_light { is_xzrect: 0, x0: 0.0, x1: 0.0, z0: 0.0, z1: 0.0, k: 0.0 },
+    };
+    let camera = rr_camera { origin: v3(cam.origin), lower_left: v3(cam.lower_left), horizontal: v3(cam.horizontal), vertical: v3(cam.vertical),
+                             u: v3(cam.u), v: v3(cam.v), lens_radius: cam.lens_radius, shutter_open: cam.shutter_open, shutter_close: cam.shutter_close };
+
+    fn arr<T>(v: &Vec<T>) -> (u32, *const T) { (v.len() as u32, if v.is_empty() { null() } else { v.as_ptr() }) }
+    let flat = rr_flat_scene {
+        n_spheres: arr(&f.spheres).0, spheres: arr(&f.spheres).1,
+        n_moving_spheres: arr(&f.moving_spheres).0, moving_spheres: arr(&f.moving_spheres).1,
+        n_rects: arr(&f.rects).0, rects: arr(&f.rects).1,
+        n_triangles: arr(&f.triangles).0, triangles: arr(&f.triangles).1,
+        n_cuboids: arr(&f.cuboids).0, cuboids: arr(&f.cuboids).1,
+        n_media: arr(&f.media).0, media: arr(&f.media).1,
+        n_instances: arr(&f.instances).0, instances: arr(&f.instances).1,
+        n_bvh_nodes: arr(&f.bvh_nodes).0, bvh_nodes: arr(&f.bvh_nodes).1,
+        n_lists: arr(&f.lists).0, lists: arr(&f.lists).1,
+        n_child_refs: arr(&f.child_refs).0, child_refs: arr(&f.child_refs).1,
+        n_materials: arr(&f.materials).0, materials: arr(&f.materials).1,
+        n_textures: arr(&f.textures).0, textures: arr(&f.textures).1,
+        n_perlin: arr(&f.perlin).0, perlin: arr(&f.perlin).1,
+        n_images: arr(&images).0, images: arr(&images).1,
+        n_image_bytes: image_bytes.len() as u64, image_bytes: if image_bytes.is_empty() { null() } else { image_bytes.as_ptr() },
+        root, light, camera, background: v3(background),
+    };
+
+    let mut ctx = null_mut();
+    check(unsafe { rr_context_create(0, &mut ctx) });
+    check(unsafe { rr_scene_upload(ctx, &flat) });
+    let k = num_cpus::get() as u32; // render.rs:129: the 8-bit image depends on the slice count (render.rs:102-119)
+    let p = rr_render_params { width: img_width, height: img_height, samples_per_pixel: samples_per_pixel as u32, n_slices: k, slice_begin: 0,
+                               slice_end: k, max_depth: max_depth as u32, seed: rand::random(), sample_offset: 0, flags: 0 };
+    let mut rgb = vec![0u8; (img_width * img_height * 3) as usize];
+    check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
+    unsafe { rr_context_destroy(ctx) };
+    ImageBuffer::from_raw(img_width, img_height, rgb).unwrap() // row 0 = top, as render.rs:119 writes it
+}
