@@ -232,8 +232,9 @@ typedef struct rr_render_params {
  * queue of live paths), used for scenes with them.  These flags override the choice.       */
 #define RR_FLAG_PERSISTENT 2u
 #define RR_FLAG_WAVEFRONT 4u
-/* The wavefront pipeline hands the last few paths of a batch to a kernel that runs each of them to its end;
- * this flag keeps it to bounce-by-bounce launches throughout (for tests: the result is the same).      */
+/* After its first bounces the wavefront pipeline hands the paths still alive to a kernel that runs each of
+ * them to its end; this flag keeps it to bounce-by-bounce launches throughout, which makes the call
+ * synchronise with the stream after every bounce from the fourth on (for tests: the result is the same). */
 #define RR_FLAG_NO_FINISH_KERNEL 8u
 
 typedef struct rr_counters {
@@ -304,12 +305,10 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
  *   d_linear     : H × W × 3 f32, Σ over the rendered slices of the NaN-scrubbed
  *                  pixel sums (linear radiance × samples).          Optional.
  *   d_counters   : one rr_counters, ADDED to (caller zeroes it).   Optional.
- * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream).  The
- * persistent kernel is enqueued and the call returns without synchronising; the
- * wavefront pipeline launches a pair of kernels per bounce until no path is left,
- * which the host learns by synchronising with the stream after a bounce; part of
- * the work runs on a stream of the library's own, ordered against hip_stream by
- * events, so whatever the caller enqueues on hip_stream afterwards sees the result. */
+ * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream) and the
+ * call returns without synchronising.  Part of the wavefront pipeline's work runs
+ * on a stream of the library's own, ordered against hip_stream by events, so
+ * whatever the caller enqueues on hip_stream afterwards sees the result.        */
 int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
                      void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
 

@@ -692,10 +692,10 @@ int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t n_sl, ui
 }
 
 // The wavefront renderer for the slices of one pass (a.n_slots slots, absolute first slice
-// a.slice_first): batches of samples, each a bounce loop of traversal and shading launches that
-// ends when no path is left, followed by the in-order accumulation of the batch.  How many
-// bounces a batch takes is only known on the device, so the host reads the live-path count back
-// every few bounces and this function returns when the last batch's paths have ended.
+// a.slice_first): batches of samples, each a few bounces of traversal and shading launches, one
+// launch that runs the remaining paths to their ends, and the in-order accumulation of the batch.
+// Everything is enqueued; the function does not wait for the device (except under
+// RR_FLAG_NO_FINISH_KERNEL, where the host has to learn when the last path has ended).
 int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, float* sums, unsigned long long* counters, hipStream_t stream) {
     // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path).  Two workspaces
     // take turns: the last paths of a batch (whose bounces each last as long as their slowest ray while the
@@ -757,9 +757,17 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
         return rc;
     hipStream_t aux = ctx->wf_aux;
 
-    // The host learns the number of live paths by reading it back (a synchronisation with the caller's stream)
-    // after every bounce from the fourth on; when few are left, one launch of k_wf_finish runs them to their ends.
-    constexpr uint32_t POLL_FROM = 3, FINISH_FRACTION = 64, FINISH_MIN = 1u << 16;
+    // A batch takes a fixed number of bounces as pairs of launches over the queue of live paths, then one launch
+    // of k_wf_finish runs what is left to its end: nothing is read back, the whole render is only enqueued.
+    // The bounce kernels are the faster way through the first bounces of a big batch (8 waves per SIMD of pure
+    // traversal); on a small one their launch gaps and tails weigh more than that (measured, bounces 2/3/4/6:
+    // 9 M paths 2169/1853/1745/1573 Msamples/s, 128 M paths 1638/1676/1676/1653).
+    // With RR_FLAG_NO_FINISH_KERNEL it is bounce launches throughout, and the host reads the number of live
+    // paths back after every bounce from the fourth on to know when to stop.
+#ifndef RR_WF_FINISH_PATHS_PER_LANE
+#define RR_WF_FINISH_PATHS_PER_LANE 2u
+#endif
+    constexpr uint32_t POLL_FROM = 3, BOUNCES_SMALL = 2, BOUNCES_LARGE = 4, LARGE_BATCH = 1u << 25;
     uint32_t n_batches = 0;
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch), ++n_batches) {
         const int w = two ? static_cast<int>(n_batches & 1u) : 0;
@@ -770,16 +778,24 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
         // the workspace is free once the batch that used it last has been accumulated
         if (n_batches >= (two ? 2u : 1u)) HIP_TRY(hipStreamWaitEvent(stream, ctx->wf_ev_aux[w], 0));
-        uint32_t finish_live = 0;
+        uint32_t finish_bound = 0;  // upper bound of the number of paths handed to k_wf_finish (0: none are)
         const uint32_t* finish_queue = nullptr;
-        const WfCtl* finish_ctl = nullptr;
+        WfCtl* finish_ctl = nullptr;
         if (a.n_paths != 0) {
             const uint32_t path_blocks = (a.n_paths + 255u) / 256u;
             hipLaunchKernelGGL(k_wf_init, dim3(std::min<uint32_t>(path_blocks, static_cast<uint32_t>(ctx->n_cus) * 32u)), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
             HIP_TRY(hipGetLastError());
+            const bool poll = (flags & RR_FLAG_NO_FINISH_KERNEL) != 0;
+            const uint32_t bounces = a.n_paths >= LARGE_BATCH ? BOUNCES_LARGE : BOUNCES_SMALL;
             uint32_t live = a.n_paths;  // upper bound of the queue length, refreshed at every poll
             // a path ends at the latest in the ray_color call that finds its depth used up (render.rs:16)
             for (uint32_t it = 0; it <= a.max_depth; ++it) {
+                if (!poll && it == bounces) {
+                    finish_bound = std::max<uint32_t>(a.n_paths >> it, 1u << 16);
+                    finish_queue = queue[it & 1u];
+                    finish_ctl = ctl + it % 3u;
+                    break;
+                }
                 WfCtl *c_in = ctl + it % 3u, *c_out = ctl + (it + 1u) % 3u, *c_clear = ctl + (it + 2u) % 3u;
                 const uint32_t* q_in = queue[it & 1u];
                 uint32_t* q_out = queue[(it + 1u) & 1u];
@@ -792,25 +808,22 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
                     hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
                 hipLaunchKernelGGL(k_wf_shade, dim3(grid_s), dim3(256), 0, stream, ctx->sc, a, st, q_in, c_in, q_out, c_out, c_clear, counters);
                 HIP_TRY(hipGetLastError());
-                if (it >= POLL_FROM && it != a.max_depth) {
+                if (poll && it >= POLL_FROM && it != a.max_depth) {
                     HIP_TRY(hipMemcpyAsync(ctx->wf_host_count, &c_out->count, 4, hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipStreamSynchronize(stream));
                     live = *ctx->wf_host_count;
                     if (live == 0) break;
-                    if (live <= std::max(a.n_paths / FINISH_FRACTION, FINISH_MIN) && !(flags & RR_FLAG_NO_FINISH_KERNEL)) {
-                        finish_live = live;
-                        finish_queue = q_out;
-                        finish_ctl = c_out;
-                        break;
-                    }
                 }
             }
         }
         // stragglers and accumulation on the second stream, in batch order (render.rs:99 adds samples in order)
         HIP_TRY(hipEventRecord(ctx->wf_ev_main[w], stream));
         HIP_TRY(hipStreamWaitEvent(aux, ctx->wf_ev_main[w], 0));
-        if (finish_live != 0) {
-            const uint32_t grid_f = std::min<uint32_t>((finish_live + 255u) / 256u, static_cast<uint32_t>(grid_finish));
+        if (finish_bound != 0) {
+            // lanes take new paths as theirs end: fewer lanes than paths, so that the long paths do not hold whole waves
+            // (a wave that finds the queue empty leaves at once)
+            const uint32_t grid_f = std::min<uint32_t>((finish_bound + 256u * RR_WF_FINISH_PATHS_PER_LANE - 1u) / (256u * RR_WF_FINISH_PATHS_PER_LANE),
+                                                       static_cast<uint32_t>(grid_finish));
             if (count)
                 hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, ctx->root, counters);
             else
