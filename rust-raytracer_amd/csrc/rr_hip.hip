@@ -760,14 +760,15 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     // A batch takes a fixed number of bounces as pairs of launches over the queue of live paths, then one launch
     // of k_wf_finish runs what is left to its end: nothing is read back, the whole render is only enqueued.
     // The bounce kernels are the faster way through the first bounces of a big batch (8 waves per SIMD of pure
-    // traversal); on a small one their launch gaps and tails weigh more than that (measured, bounces 2/3/4/6:
-    // 9 M paths 2169/1853/1745/1573 Msamples/s, 128 M paths 1638/1676/1676/1653).
+    // traversal); on a small one their launch gaps and tails weigh more than that (measured, random spheres with
+    // 9 M paths, bounces 1/2/3/4/6: 2358/2169/1853/1745/1573 Msamples/s; Suzanne with 128 M paths, bounces 2/3/4/6:
+    // 1638/1676/1676/1653; with 10 M paths 0, 1 or 2 bounces are best depending on the scene).
     // With RR_FLAG_NO_FINISH_KERNEL it is bounce launches throughout, and the host reads the number of live
     // paths back after every bounce from the fourth on to know when to stop.
 #ifndef RR_WF_FINISH_PATHS_PER_LANE
 #define RR_WF_FINISH_PATHS_PER_LANE 2u
 #endif
-    constexpr uint32_t POLL_FROM = 3, BOUNCES_SMALL = 2, BOUNCES_LARGE = 4, LARGE_BATCH = 1u << 25;
+    constexpr uint32_t POLL_FROM = 3, BOUNCES_SMALL = 1, BOUNCES_LARGE = 4, LARGE_BATCH = 1u << 25;
     uint32_t n_batches = 0;
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch), ++n_batches) {
         const int w = two ? static_cast<int>(n_batches & 1u) : 0;
