@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 
 // The stragglers of a batch.  Once few paths are left, a bounce costs two launches that each last as long
 // as their slowest ray while the chip idles; this kernel runs every remaining path to its end instead, a
-// lane per path, bounce after bounce like k_render (same machine, same shade, same random streams).  Path
+// lane per path, bounce after bounce like k_render (same scene program and machine, same shade, same random streams).  Path
 // lengths differ widely here (these are the long ones), so a lane whose path has ended takes the next
 // unclaimed queue entry at once: the wave's loop is uniform, one bounce per turn for every lane that has a
 // path, and the queue is claimed a chunk at a time per wave as in k_wf_traverse.  (Letting the lanes of a
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 // was measured equal on the Suzanne scene and 4-10 % slower on final_scene.)
 template <bool COUNT>
 __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
-                                                                                WfCtl* ctl, uint32_t root, unsigned long long* counters) {
+                                                                                WfCtl* ctl, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
@@ -386,17 +386,19 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
             if (exhausted) break;
             continue;
         }
-        // one ray_color call (render.rs:15-41) for every lane that has a path
+        // one ray_color call (render.rs:15-41) for every lane that has a path.  The lanes start their rays
+        // together, so the part of the tree every ray visits is walked by the scene program, with scalar
+        // control flow and scalar loads, and only the BVH subtrees run on the per-lane machine.
         const bool run = have && depth_left != 0;
+        if (run) cnt.rays++;
+        Rng g;
+        g.start(a.seed, pixel, sample, a.max_depth - depth_left);
+        float t;
+        uint32_t ref;
+        traverse<COUNT, true>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
         if (run) {
-            cnt.rays++;
-            Rng g;
-            g.start(a.seed, pixel, sample, a.max_depth - depth_left);
-            float t = kF32Max;
-            uint32_t ref = NONE;
-            machine<COUNT>(sc, root, ro, rd, ro, rd, time, 0.001f, t, ref, g, stk, stride, cnt);
             Bounce b;
             go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
             if (go_on) {
