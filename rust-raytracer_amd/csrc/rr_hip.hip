@@ -271,15 +271,15 @@ struct rr_context {
     bool timed = false;
     int max_dynamic_lds = 0;
     // wavefront renderer: whether the scene has BVH subtrees, its root for the traversal machine,
-    // and a grow-only workspace (path state, two queues, queue controls) with a pinned word the
-    // host polls the live-path count through
+    // and a grow-only workspace (path state, two queues, queue controls) with a pinned word through
+    // which the host reads the live-path count when it has to (RR_FLAG_NO_FINISH_KERNEL)
     bool has_subtrees = false;
     bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
     uint32_t root = NONE;
     void* wf_mem = nullptr;
     size_t wf_bytes = 0;
     uint32_t* wf_host_count = nullptr;
-    hipStream_t wf_aux = nullptr;                 // the stragglers and the accumulation of a batch run here, beside the next batch
+    hipStream_t wf_aux = nullptr;                 // k_wf_finish and the accumulation of a batch run here, beside the next batch
     hipEvent_t wf_ev_main[2] = {nullptr, nullptr};  // per workspace: the batch's bounce loop is enqueued
     hipEvent_t wf_ev_aux[2] = {nullptr, nullptr};   // per workspace: the batch is accumulated, the workspace is free
 };
@@ -820,7 +820,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
                 }
             }
         }
-        // stragglers and accumulation on the second stream, in batch order (render.rs:99 adds samples in order)
+        // the rest of the batch's paths and its accumulation on the second stream, in batch order (render.rs:99 adds samples in order)
         HIP_TRY(hipEventRecord(ctx->wf_ev_main[w], stream));
         HIP_TRY(hipStreamWaitEvent(aux, ctx->wf_ev_main[w], 0));
         if (finish_bound != 0) {

@@ -4,8 +4,9 @@
 // The persistent kernel k_render keeps a lane on its path from camera ray to termination, which
 // is ideal while all 64 rays of a wave take the same steps through the scene.  Below a BVH they
 // do not: traversal lengths differ by an order of magnitude between neighbouring rays, and a wave
-// is as slow as its longest ray.  Here a path's state lives in device memory between bounces and
-// each bounce is two kernels over a compacted queue of live paths:
+// is as slow as its longest ray.  Here a path's state lives in device memory between bounces, the
+// first bounce or two of a batch are two kernels each over a compacted queue of live paths, and
+// one more kernel runs what is left of every path:
 //
 //   k_wf_traverse  persistent waves; a lane takes a ray from the queue, runs the traversal machine
 //                  over the whole scene tree, stores (t, primitive) and takes the next ray, so a
@@ -14,6 +15,8 @@
 //   k_wf_shade     one thread per live path: ray_color's work after scene.intersect
 //                  (render.rs:19-40); a path that goes on is appended to the next bounce's queue,
 //                  one that ends leaves its sample value (throughput x terminal colour) behind
+//   k_wf_finish    a lane per remaining path, bounce after bounce to the path's end; lanes whose
+//                  path has ended take the next one from the queue
 //
 // Paths are independent, so many samples of a pixel are in flight at once: a pass covers a batch
 // of consecutive samples of every (slice, pixel) pair (a "slot"), runs until every path has
@@ -333,9 +336,9 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 #define RR_WF_FINISH_WAVES_PER_SIMD 4
 #endif
 
-// The stragglers of a batch.  Once few paths are left, a bounce costs two launches that each last as long
-// as their slowest ray while the chip idles; this kernel runs every remaining path to its end instead, a
-// lane per path, bounce after bounce like k_render (same scene program and machine, same shade, same random streams).  Path
+// The rest of a batch after its first bounces.  With every bounce fewer paths are left, and a bounce costs
+// two launches that each last as long as their slowest ray; this kernel runs every remaining path to its end
+// instead, a lane per path, bounce after bounce like k_render (same scene program and machine, same shade, same random streams).  Path
 // lengths differ widely here (these are the long ones), so a lane whose path has ended takes the next
 // unclaimed queue entry at once: the wave's loop is uniform, one bounce per turn for every lane that has a
 // path, and the queue is claimed a chunk at a time per wave as in k_wf_traverse.  (Letting the lanes of a

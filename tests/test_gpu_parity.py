@@ -292,7 +292,7 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
 
 def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch):
     """Many small batches (the workspace is capped for the test), alternating between the two workspaces, the
-    stragglers and the accumulation of one running beside the bounces of the next: same bits as one lane per
+    rest of the paths and the accumulation of one running beside the bounces of the next: same bits as one lane per
     pixel summing its samples in order."""
     b, flat, _ = config_scene("suzanne")
     gpu_ctx.upload(flat)
