@@ -305,6 +305,21 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
         assert one["counters"] == two["counters"]
 
 
+@pytest.mark.parametrize("name,side,spp", [("suzanne", 640, 96), ("final", 512, 136)])
+def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp):
+    """A batch of more than 2^25 paths (the size from which a scene without media takes two pairs of bounce launches
+    before the kernel that finishes the paths; a scene with media always takes one): same bits as the persistent kernel."""
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=8, max_depth=25, seed=41)
+    assert side * side * spp >= 1 << 25
+    one = gpu_ctx.render(device.make_params(side, side, spp, flags=abi.FLAG_PERSISTENT, **kw))
+    two = gpu_ctx.render(device.make_params(side, side, spp, flags=abi.FLAG_WAVEFRONT, **kw))
+    assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
+    assert np.array_equal(one["rgb8"], two["rgb8"])
+    assert one["counters"] == two["counters"]
+
+
 # --------------------------------------------------- size-independent properties
 def test_render_is_deterministic_and_slices_compose(gpu_ctx):
     """Bit-identical reruns; rendering slice ranges separately equals rendering them together; a
