@@ -714,7 +714,7 @@ __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const Worl
             if (found) {  // collider.rs:448-474
                 if (t1 < m.tmin) t1 = m.tmin;
                 if (t2 > m.tmax) t2 = m.tmax;
-                if (t1 < t2) {
+                if (!(t1 >= t2)) {  // collider.rs:454 returns on `t1 >= t2`: a NaN bound goes on
                     if (t1 < 0.0f) t1 = 0.0f;
                     const float ray_length = len3(m.d);
                     const float dist_inside = (t2 - t1) * ray_length;
@@ -938,7 +938,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
             if (found) {
                 if (t1 < tmin) t1 = tmin;
                 if (t2 > tmax) t2 = tmax;
-                if (t1 < t2) {
+                if (!(t1 >= t2)) {  // collider.rs:454 returns on `t1 >= t2`: a NaN bound goes on
                     if (t1 < 0.0f) t1 = 0.0f;
                     const float ray_length = len3(d);
                     const float dist_inside = (t2 - t1) * ray_length;

@@ -144,6 +144,20 @@ def _random_scene(seed):
     b.add(group(int(rng.integers(1, 200)), 50.0))
     b.add(b.collider_list([prim(10.0), b.instance_translation(group(int(rng.integers(2, 30)), 3.0), rng.uniform(-40, 40, 3))]))
     b.add(b.sphere((0, -1000, 0), 990.0, mats[0]))  # a huge sphere next to the small ones
+    # textured surfaces and media with other boundaries than a sphere, at the top level and below instances
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    tex = [b.lambertian(b.checkered((0.1, 0.2, 0.3), (0.9, 0.8, 0.7))), b.lambertian(b.noise(2.5, 5)),
+           b.lambertian(b.load_image_rgb8(img)), b.isotropic((0.6, 0.7, 0.8))]
+    for m in tex:
+        c = rng.uniform(-30, 30, 3)
+        b.add(b.sphere(c, float(rng.uniform(2, 8)), m))
+        b.add(b.instance_rotation(b.xzrect(c[0], c[0] + 9, c[2], c[2] + 7, float(c[1]), m), int(rng.integers(0, 3)), float(rng.uniform(-90, 90))))
+    c = rng.uniform(-25, 25, 3)
+    b.add(b.constant_medium(b.cuboid(c, c + rng.uniform(3, 15, 3), mats[0]), 0.15, (0.9, 0.9, 0.9)))
+    two = b.bvh_node([b.sphere(c + 20, 6.0, mats[0]), b.sphere(c + 24, 5.0, mats[0])])
+    b.add(b.instance_translation(b.constant_medium(two, 0.3, (0.2, 0.3, 0.4)), rng.uniform(-10, 10, 3)))
+    b.add(b.constant_medium(b.instance_translation(b.instance_rotation(b.sphere((0, 0, 0), 9.0, mats[0]), 1, 30.0), rng.uniform(-30, 30, 3)),
+                            0.1, (1, 1, 1)))
     b.set_lights(b.xzrect(-5, 5, -5, 5, 60.0, mats[3]))
     b.set_camera((0, 20, -120), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
     b.set_background((0.5, 0.6, 0.9))
