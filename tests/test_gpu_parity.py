@@ -109,7 +109,10 @@ def _random_scene(seed):
             b.emissive((4, 4, 4))]
 
     def mat():
-        return mats[int(rng.integers(0, len(mats)))]
+        i = int(rng.integers(0, len(mats)))
+        if seed % 2 == 1 and rng.random() < 0.6:
+            i = 0  # odd seeds: mostly Lambertian surfaces, so that few samples are NaN (render.rs:34 with pdf 0)
+        return mats[i]
 
     def prim(scale):
         c = rng.uniform(-scale, scale, 3)
@@ -158,6 +161,16 @@ def _random_scene(seed):
     b.add(b.instance_translation(b.constant_medium(two, 0.3, (0.2, 0.3, 0.4)), rng.uniform(-10, 10, 3)))
     b.add(b.constant_medium(b.instance_translation(b.instance_rotation(b.sphere((0, 0, 0), 9.0, mats[0]), 1, 30.0), rng.uniform(-30, 30, 3)),
                             0.1, (1, 1, 1)))
+    # a chain of seven instances around a small BVH, and a list inside a list (a list has no box, so none inside a BVH)
+    deep = group(int(rng.integers(2, 12)), 4.0)
+    for i in range(7):
+        deep = (b.instance_rotation(deep, int(rng.integers(0, 3)), float(rng.uniform(-60, 60))) if i % 2 == 0
+                else b.instance_translation(deep, rng.uniform(-6, 6, 3)))
+    b.add(deep)
+    c = rng.uniform(-40, 40, 3)  # (no degenerate triangle here: outside a BVH it would turn every ray of the scene into NaN)
+    b.add(b.collider_list([b.sphere(c, 3.0, mat()), b.collider_list([b.yzrect(c[1], c[1] + 5, c[2], c[2] + 6, float(c[0]) - 8, mat()),
+                                                                       group(3, 2.0), b.sphere(c + 7, 2.0, mat())]),
+                           b.cuboid(c - 9, c - 5, mat())]))
     b.set_lights(b.xzrect(-5, 5, -5, 5, 60.0, mats[3]))
     b.set_camera((0, 20, -120), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
     b.set_background((0.5, 0.6, 0.9))
@@ -179,20 +192,23 @@ def test_production_traversal_on_random_scenes(gpu_ctx, seed):
     assert sum(info["bvh_nodes_by_class"]) > 0
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(8))
 def test_renders_of_random_scenes_agree_between_all_kernel_forms(gpu_ctx, seed):
     """Whole paths (bounce rays start on surfaces, inside media, at grazing angles) through randomly assembled
     scenes: production kernels, reference-order kernels and the persistent kernel produce the same bits."""
     b, flat = _random_scene(40 + seed)
     gpu_ctx.upload(flat)
-    kw = dict(n_slices=2, max_depth=25, seed=3)
+    kw = dict(n_slices=8, max_depth=25, seed=3)  # one sample per slice: a NaN sample (render.rs:34 with pdf 0) spoils only itself
     base = gpu_ctx.render(device.make_params(48, 40, 8, **kw))
     for flags in (abi.FLAG_COUNTERS, abi.FLAG_PERSISTENT, abi.FLAG_PERSISTENT | abi.FLAG_COUNTERS, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL):
         other = gpu_ctx.render(device.make_params(48, 40, 8, flags=flags, **kw))
         assert np.array_equal(base["slice_sums"], other["slice_sums"], equal_nan=True), flags
     want = O.render(flat, O.make_params(48, 40, 8, **kw), n_threads=8)
-    both = ~np.isnan(base["slice_sums"]) & ~np.isnan(want["slice_sums"])
-    assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.95
+    nan_got, nan_want = np.isnan(base["slice_sums"]), np.isnan(want["slice_sums"])
+    assert (nan_got == nan_want).mean() > 0.995
+    both = ~nan_got & ~nan_want
+    assert both.mean() > 0.05, "too few samples without NaN to compare"
+    assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.995
 
 
 # ------------------------------------------------------------ whole renders
