@@ -921,7 +921,9 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
         } else if (VEC && code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
             if (live) eval_leaf<COUNT>(sc, uni(op.ref), o, d, time, tmin, tmax, cur, cnt);
         } else if (VEC && code == OP_SUBTREE) {  // BVH (or any shape the program does not flatten): per-lane machine
+#ifndef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             if (live) machine<COUNT>(sc, uni(op.ref), wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
+#endif
         } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
             if (COUNT && live) cnt.inst_visits++;
             m_tmin = tmin, m_tmax = tmax, m_cur = cur;
@@ -953,6 +955,169 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
     }
     t_hit = tmax;
     ref_hit = cur;
+}
+
+// The same interpreter for a kernel whose lanes may leave a BVH subtree unfinished and come back to it in
+// a later call ("parking").  A wave waits in OP_SUBTREE for the deepest descent among its lanes; when only
+// a few lanes are still descending, waiting wastes the others.  Here those few keep their traversal state
+// (machine registers, LDS stack, the interpreter state below) and sit out the rest of the call; in the next
+// call of the wave they skip the ops before the subtree they are parked at, join the lanes that enter it
+// then, and go on with the rest of the program once their descent is complete.  Every lane still executes
+// its own ops in program order on its own state, so the result is the one traverse() computes.
+struct ProgState {
+    f3 o, d;  // the ray in the space the program is in
+    float tmin, tmax;
+    uint32_t cur;
+    bool live;
+    float m_tmin, m_tmax, m_t1;  // the enclosing call's range and probe 1 of the open medium
+    uint32_t m_cur;
+    Trav m;
+    uint32_t park_pc;  // the OP_SUBTREE this lane is parked at
+    bool parked;
+    __device__ __forceinline__ void start(f3 wo, f3 wd, float tmin_, float tmax_) {
+        o = wo, d = wd;
+        tmin = tmin_, tmax = tmax_;
+        cur = NONE;
+        live = true;
+        m_tmin = m_tmax = m_t1 = 0.0f;
+        m_cur = NONE;
+        parked = false;
+        park_pc = 0;
+    }
+};
+
+// `enabled`: the lane has a ray, started with ProgState::start() before this call or parked by an earlier one.
+// `park_below`: lanes still descending are parked once fewer than this many are left (0: never park), but not
+// before `min_steps` machine steps have been taken in this visit, so that parked lanes always make progress.
+// On return a lane with s.parked set has no result yet; the others have theirs in (s.tmax, s.cur).
+template <bool COUNT>
+__device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, bool enabled, ProgState& s, Rng& rng,
+                                                 uint32_t* stk, uint32_t stride, uint32_t park_below, uint32_t min_steps, Counts& cnt) {
+    bool act = enabled && !s.parked;  // the lane executes the ops it comes to
+    const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
+    Op next = prog[0];
+    uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
+    const WorldInRegs world{wo, wd, time};
+    for (;;) {
+        const Op op = next;
+        const uint32_t this_pc = pc;
+        pc = uni(pc + 1);
+        next = prog[pc];
+        const uint32_t code = uni(op.code) & 0xFFu;
+        if (code == OP_END) break;
+        if (code == OP_SUBTREE) {
+            const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
+            const bool enter = act && s.live;
+            if (enter) s.m.begin(uni(op.ref), s.o, s.d, s.tmin, s.tmax, s.cur);
+            const bool in = enter || rejoin;
+            uint32_t steps = 0;
+            for (;;) {
+                const bool going = in && !s.m.finished();
+                const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
+                if (n == 0 || (n < park_below && steps >= min_steps)) break;
+                if (going) trav_step<COUNT>(sc, s.m, world, rng, stk, stride, cnt);
+                steps += 1;
+            }
+            if (in) {
+                if (s.m.finished()) {
+                    s.tmax = s.m.tmax;
+                    s.cur = s.m.cur;
+                    s.parked = false;
+                    act = true;
+                } else {
+                    s.parked = true;
+                    s.park_pc = this_pc;
+                    act = false;
+                }
+            }
+        } else if (act) {
+            if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
+                if (COUNT && s.live) cnt.rect_tests++;
+                float t;
+                bool hit;
+                if (code == OP_RECT_XY)
+                    hit = test_rect_axis<RR_RECT_XY>(op.f0, op.f1, op.f2, op.f3, op.f4, s.o, s.d, s.tmin, s.tmax, t);
+                else if (code == OP_RECT_XZ)
+                    hit = test_rect_axis<RR_RECT_XZ>(op.f0, op.f1, op.f2, op.f3, op.f4, s.o, s.d, s.tmin, s.tmax, t);
+                else
+                    hit = test_rect_axis<RR_RECT_YZ>(op.f0, op.f1, op.f2, op.f3, op.f4, s.o, s.d, s.tmin, s.tmax, t);
+                hit &= s.live;
+                s.tmax = hit ? t : s.tmax;
+                s.cur = hit ? op.ref : s.cur;
+            } else if (code == OP_CUBOID) {  // collider.rs:428-430: the six sides in the constructor's order (collider.rs:419-426)
+                if (COUNT && s.live) cnt.rect_tests += 6;
+                float t;
+                uint32_t side = NONE;
+                const bool live = s.live;
+                if (test_rect_axis<RR_RECT_XY>(op.f0, op.f3, op.f1, op.f4, op.f5, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 0;
+                if (test_rect_axis<RR_RECT_XY>(op.f0, op.f3, op.f1, op.f4, op.f2, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 1;
+                if (test_rect_axis<RR_RECT_XZ>(op.f0, op.f3, op.f2, op.f5, op.f4, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 2;
+                if (test_rect_axis<RR_RECT_XZ>(op.f0, op.f3, op.f2, op.f5, op.f1, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 3;
+                if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f3, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 4;
+                if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f0, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 5;
+                if (live && side != NONE) s.cur = op.ref + side;
+            } else if (code == OP_RESET) {
+                s.o = wo;
+                s.d = wd;
+            } else if (code == OP_TRANSLATE) {  // collider.rs:481
+                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+                s.o = s.o - mk3(op.f0, op.f1, op.f2);
+            } else if (code >= OP_ROT_X && code <= OP_ROT_Z) {  // collider.rs:499-509
+                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+                const float sn = op.f0, c = op.f1;
+                const f3 o = s.o, d = s.d;
+                f3 no = o, nd = d;
+                if (code == OP_ROT_Y) {
+                    no.x = c * o.x - sn * o.z, no.z = sn * o.x + c * o.z;
+                    nd.x = c * d.x - sn * d.z, nd.z = sn * d.x + c * d.z;
+                } else if (code == OP_ROT_X) {
+                    no.y = c * o.y - sn * o.z, no.z = sn * o.y + c * o.z;
+                    nd.y = c * d.y - sn * d.z, nd.z = sn * d.y + c * d.z;
+                } else {
+                    no.x = c * o.x - sn * o.y, no.y = sn * o.x + c * o.y;
+                    nd.x = c * d.x - sn * d.y, nd.y = sn * d.x + c * d.y;
+                }
+                s.o = no;
+                s.d = nd;
+            } else if (code == OP_SPHERE) {
+                if (COUNT && s.live) cnt.sphere_tests++;
+                float t;
+                if (test_sphere(mk3(op.f0, op.f1, op.f2), op.f3, s.o, s.d, s.tmin, s.tmax, t) && s.live) {
+                    s.tmax = t;
+                    s.cur = op.ref;
+                }
+            } else if (code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
+                if (s.live) eval_leaf<COUNT>(sc, uni(op.ref), s.o, s.d, time, s.tmin, s.tmax, s.cur, cnt);
+            } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
+                if (COUNT && s.live) cnt.inst_visits++;
+                s.m_tmin = s.tmin, s.m_tmax = s.tmax, s.m_cur = s.cur;
+                s.tmin = -kF32Max, s.tmax = kF32Max, s.cur = NONE;
+            } else if (code == OP_MED_MID) {  // collider.rs:443: second probe over (t1 + 0.0001, f32::MAX)
+                s.live = s.cur != NONE;
+                s.m_t1 = s.tmax;
+                s.tmin = s.m_t1 + 0.0001f, s.tmax = kF32Max, s.cur = NONE;
+            } else {  // OP_MED_END, collider.rs:448-474
+                const bool found = s.live && s.cur != NONE;
+                float t1 = s.m_t1, t2 = s.tmax;
+                s.tmin = s.m_tmin, s.tmax = s.m_tmax, s.cur = s.m_cur;
+                s.live = true;
+                if (found) {
+                    if (t1 < s.tmin) t1 = s.tmin;
+                    if (t2 > s.tmax) t2 = s.tmax;
+                    if (!(t1 >= t2)) {  // collider.rs:454 returns on `t1 >= t2`: a NaN bound goes on
+                        if (t1 < 0.0f) t1 = 0.0f;
+                        const float ray_length = len3(s.d);
+                        const float dist_inside = (t2 - t1) * ray_length;
+                        const float hit_dist = op.f0 * log10f(rng.random());
+                        if (!(hit_dist > dist_inside)) {
+                            s.tmax = t1 + hit_dist / ray_length;
+                            s.cur = op.ref;
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------- hit records

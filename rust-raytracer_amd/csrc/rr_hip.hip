@@ -757,21 +757,20 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
         return rc;
     hipStream_t aux = ctx->wf_aux;
 
-    // A batch takes its first one or two bounces as pairs of launches over the queue of live paths, then one
-    // launch of k_wf_finish runs what is left to its end: nothing is read back, the whole render is only
-    // enqueued.  The bounce kernels are the faster way through the camera rays and, on a big batch, the bounce
-    // after them (8 waves per SIMD of pure traversal with lanes refilled in mid-flight); k_wf_finish walks the
-    // part of the tree every ray visits with the scene program, which weighs more the more there is of it,
-    // and takes no launch gaps and tails.  Measured, Msamples/s with 0/1/2/3/4 bounce pairs: Suzanne 128 M
-    // paths 1744/1756/1788/1771/1745; final_scene 102 M paths 1098/1192/1075/1052/1041 (a medium costs the
-    // bounce kernels a Philox block per draw); random spheres 36 M paths 2331/2693/2916/2736/2580, 9 M paths
-    // 2079/2247/2288/2312/-; Suzanne 10 M paths 1185/1107/-; final_scene 10 M paths 769/916/-.
+    // A batch takes its camera rays as one pair of launches over the queue of all its paths, then one launch of
+    // k_wf_finish runs what is left to its end: nothing is read back, the whole render is only enqueued.
+    // The bounce kernels are the faster way through the camera rays (8 waves per SIMD of pure traversal with
+    // lanes refilled in mid-flight, coherent rays); from the second ray on k_wf_finish is: it walks the part of
+    // the tree every ray visits with the scene program, pays no launch gaps and tails, and parks the few lanes
+    // with deep BVH descents instead of waiting for them.  Measured, Msamples/s with 0/1/2/3 pairs of bounce
+    // launches: Suzanne 128 M paths 1975/2137/1965/1851; final_scene 102 M paths 1043/1180/1188/1192; random
+    // spheres 36 M paths 2234/2856/2902/2739, 9 M paths 2070/2407/-/-.
     // With RR_FLAG_NO_FINISH_KERNEL it is bounce launches throughout, and the host reads the number of live
     // paths back after every bounce from the fourth on to know when to stop.
 #ifndef RR_WF_FINISH_PATHS_PER_LANE
 #define RR_WF_FINISH_PATHS_PER_LANE 2u
 #endif
-    constexpr uint32_t POLL_FROM = 3, LARGE_BATCH = 1u << 25;
+    constexpr uint32_t POLL_FROM = 3;
     uint32_t n_batches = 0;
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch), ++n_batches) {
         const int w = two ? static_cast<int>(n_batches & 1u) : 0;
@@ -790,7 +789,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
             hipLaunchKernelGGL(k_wf_init, dim3(std::min<uint32_t>(path_blocks, static_cast<uint32_t>(ctx->n_cus) * 32u)), dim3(256), 0, stream, ctx->sc, a, st, queue[0], ctl, counters);
             HIP_TRY(hipGetLastError());
             const bool poll = (flags & RR_FLAG_NO_FINISH_KERNEL) != 0;
-            const uint32_t bounces = (a.n_paths >= LARGE_BATCH && ctx->id_medium.empty()) ? 2u : 1u;
+            const uint32_t bounces = 1;
             uint32_t live = a.n_paths;  // upper bound of the queue length, refreshed at every poll
             // a path ends at the latest in the ray_color call that finds its depth used up (render.rs:16)
             for (uint32_t it = 0; it <= a.max_depth; ++it) {

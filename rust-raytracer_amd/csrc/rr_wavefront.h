@@ -333,7 +333,16 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 }
 
 #ifndef RR_WF_FINISH_WAVES_PER_SIMD
-#define RR_WF_FINISH_WAVES_PER_SIMD 4
+#define RR_WF_FINISH_WAVES_PER_SIMD 3
+#endif
+#ifndef RR_WF_FINISH_PARK_BELOW
+#define RR_WF_FINISH_PARK_BELOW 12  // lanes still descending in a subtree are parked once fewer than this many are left
+#endif
+#ifndef RR_WF_FINISH_PARK_MIN_STEPS
+#define RR_WF_FINISH_PARK_MIN_STEPS 4  // machine steps a visit of a subtree takes at least, so that parked lanes get on
+#endif
+#ifndef RR_WF_FINISH_PARK_MIN_FRESH
+#define RR_WF_FINISH_PARK_MIN_FRESH 8  // with the queue drained and fewer lanes than this starting a ray, nothing is parked
 #endif
 
 // The rest of a batch after its first bounces.  With every bounce fewer paths are left, and a bounce costs
@@ -357,9 +366,12 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
     bool exhausted = total == 0;            // wave-uniform: no unclaimed entries are left for anyone
     bool have = false;
-    uint32_t p = 0, depth_left = 0, pixel = 0, sample = 0;
+    uint32_t p = 0, depth_left = 0, pixel = 0, sample = 0, draws = 0;
     f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(1.f, 1.f, 1.f), thr = mk3(0.f, 0.f, 0.f);
     float time = 0.f;
+    ProgState ps;
+    ps.start(ro, rd, 0.f, 0.f);
+    ps.m.begin(NONE, ro, rd, 0.f, 0.f, NONE);
     for (;;) {
         const uint64_t idle = __ballot(!have);
         if (!exhausted && idle != 0) {
@@ -383,37 +395,47 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                 depth_left = __float_as_uint(qd.w);
                 wf_path_key(a, p, pixel, sample);
                 have = true;
+                draws = 0;
+                ps.start(ro, rd, 0.001f, kF32Max);
             }
         }
         if (!__any(have)) {
             if (exhausted) break;
             continue;
         }
-        // one ray_color call (render.rs:15-41) for every lane that has a path.  The lanes start their rays
+        // One ray_color call (render.rs:15-41) for every lane that has a path.  The lanes start their rays
         // together, so the part of the tree every ray visits is walked by the scene program, with scalar
-        // control flow and scalar loads, and only the BVH subtrees run on the per-lane machine.
+        // control flow and scalar loads, and only the BVH subtrees run on the per-lane machine.  The few lanes
+        // with the deepest descents are parked in their subtree rather than waited for (traverse_parking):
+        // they finish it in later turns, beside the lanes that enter it then, unless the wave has little else to do.
         const bool run = have && depth_left != 0;
-        if (run) cnt.rays++;
+        if (run && !ps.parked) cnt.rays++;
         Rng g;
         g.start(a.seed, pixel, sample, a.max_depth - depth_left);
-        float t;
-        uint32_t ref;
-        traverse<COUNT, true>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+        g.n = draws;
+        if (g.n & 3u) g.refill();
+        const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !ps.parked)));
+        const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
+        traverse_parking<COUNT>(sc, ro, rd, time, run, ps, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt);
+        draws = g.n;
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
-        if (run) {
+        const bool parked = run && ps.parked;
+        if (run && !parked) {
             Bounce b;
-            go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
+            go_on = shade(sc, ro, rd, time, ps.tmax, ps.cur, ps.cur == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ps.cur), g, b);
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
                 thr = thr * b.weight;
                 depth_left -= 1;
+                draws = 0;
+                ps.start(ro, rd, 0.001f, kF32Max);
             } else {
                 terminal = b.terminal;
             }
         }
-        if (have && !go_on) {
+        if (have && !go_on && !parked) {
             const f3 c = thr * terminal;  // the sample's value (render.rs:99 adds it to the pixel)
             st.thr[p] = make_float4(c.x, c.y, c.z, 0.f);
             have = false;

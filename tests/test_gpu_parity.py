@@ -370,8 +370,8 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
 
 @pytest.mark.parametrize("name,side,spp", [("suzanne", 640, 96), ("final", 512, 136)])
 def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp):
-    """A batch of more than 2^25 paths (the size from which a scene without media takes two pairs of bounce launches
-    before the kernel that finishes the paths; a scene with media always takes one): same bits as the persistent kernel."""
+    """A batch of more than 2^25 paths, deep enough for many lanes of the kernel that finishes the paths to be parked
+    in a BVH and to come back to it: same bits as the persistent kernel."""
     b, flat, _ = config_scene(name)
     gpu_ctx.upload(flat)
     kw = dict(n_slices=8, max_depth=25, seed=41)
