@@ -200,7 +200,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         # scenes without BVH nodes are one launch of the persistent kernel; scenes with them go through the
         # wavefront pipeline, whose launches (two per bounce) the HIP events bracket as a whole
-        kernel_name = ("wavefront pipeline: k_wf_init + (k_wf_traverse<false> + k_wf_shade) x 1 or 2 bounces + k_wf_finish<false> + k_wf_accumulate"
+        kernel_name = ("wavefront pipeline: k_wf_init + k_wf_traverse<false> + k_wf_shade (camera rays) + k_wf_finish<false> + k_wf_accumulate"
                        if info["wavefront"] else "k_render<false, false> (persistent kernel, counters off, no per-lane record fetches)")
         alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9

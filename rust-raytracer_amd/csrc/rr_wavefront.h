@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 }
 
 #ifndef RR_WF_FINISH_WAVES_PER_SIMD
-#define RR_WF_FINISH_WAVES_PER_SIMD 3
+#define RR_WF_FINISH_WAVES_PER_SIMD 4
 #endif
 #ifndef RR_WF_FINISH_PARK_BELOW
 #define RR_WF_FINISH_PARK_BELOW 12  // lanes still descending in a subtree are parked once fewer than this many are left
