@@ -1,4 +1,4 @@
-"""pyoracle — a second, independent CPU restatement of the reference's intersection code.
+"""pyoracle — a second, independent CPU restatement of the reference's intersection and path code.
 
 TEST INFRASTRUCTURE ONLY (fixture generator and cross-check of oracle/rr_oracle.cpp).
 
@@ -8,7 +8,9 @@ and recurses through it exactly as `Geometry::intersect` does (collider.rs:682-6
 numpy float32 scalar arithmetic (every operation rounds to f32, no fused multiply-add).
 It also restates the host-side BVH builder (collider.rs:173-212), the Perlin table
 generation (perlin.rs:14-46) and the host PCG32 generator, so that a tree built here from
-the same seed must flatten to the same primitive ids as the C++ host library's.
+the same seed must flatten to the same primitive ids as the C++ host library's, and
+ray_color with the materials, textures and pdfs below it (render.rs:15-41, material.rs:85-181,
+pdf.rs:5-70, texture.rs:66-103) over the path random streams rr_oracle.cpp uses.
 
 Pure-Python loops: use for small cases only (a few thousand rays).
 
@@ -599,3 +601,190 @@ def xzrect_pdf_value(x0, x1, z0, z1, k, origin, v):  # collider.rs:389-399
     dist_sqrd = h.t * h.t * dot(r.d, r.d)
     cosine = abs(dot(r.d, h.n) / length(r.d))
     return dist_sqrd / (cosine * area)
+
+
+# ------------------------------------------------------------- whole paths
+# Second restatement of ray_color and what it calls (render.rs:15-41, material.rs:85-181, pdf.rs:5-70,
+# texture.rs:66-103, camera.rs:76-84), written from the Rust text and independent of rr_oracle.cpp.  It uses
+# the same random-number protocol (one Philox stream per (pixel, sample, bounce); draws that cannot reach the
+# result are not taken), so the two can be compared sample for sample.
+#
+# Materials are tuples attached to primitives and media as `g.material`:
+#   ("lambertian", tex) ("glossy", rgb, fuzz) ("dielectric", ior) ("isotropic", tex) ("emissive", tex)
+# Textures: ("solid", rgb) ("checker", odd, even) ("noise", (vec, perms), scale, depth) ("image", HxWx3 uint8)
+CAMERA_BOUNCE = 0xFFFFFFFF
+
+
+def _stream_randrange(rnd, lo, hi):  # utils.rs:45-47
+    lo, hi = f32(lo), f32(hi)
+    while True:
+        v = rnd() * (hi - lo) + lo
+        if v < hi:
+            return v
+
+
+def materials_by_prim(roots):
+    """prim id → material, walking the tree as number_primitives does; cuboid sides carry the cuboid's material."""
+    out = {}
+
+    def visit(g, inherited=None):
+        k = g.kind
+        m = getattr(g, "material", None) or inherited
+        if k in ("sphere", "moving_sphere", "xyrect", "xzrect", "yzrect", "triangle"):
+            out[g.prim] = m
+        elif k == "cuboid":
+            for s in g.sides:
+                visit(s, m)
+        elif k == "medium":
+            out[g.prim] = m
+            visit(g.boundary)
+        elif k in ("translate", "rotate"):
+            visit(g.child)
+        elif k == "bvh":
+            visit(g.left)
+            if g.right is not g.left:
+                visit(g.right)
+        elif k == "list":
+            for it in g.items:
+                visit(it)
+
+    for r in roots:
+        visit(r)
+    return out
+
+
+def _clamp(x, lo, hi):  # utils.rs:57-65
+    if x < lo:
+        return lo
+    if x > hi:
+        return hi
+    return x
+
+
+def _as_u32(x):  # Rust `as u32`: saturating, NaN → 0
+    if not (x > 0):
+        return 0
+    if x >= 4294967296.0:
+        return 0xFFFFFFFF
+    return int(x)
+
+
+def texture_color(tex, u, v, p):  # texture.rs:66-103
+    kind = tex[0]
+    if kind == "solid":
+        return v3(*tex[1])
+    if kind == "checker":
+        sines = np.sin(f32(10) * p[0]) * np.sin(f32(10) * p[1]) * np.sin(f32(10) * p[2])
+        return v3(*tex[1]) if sines < f32(0) else v3(*tex[2])
+    if kind == "noise":
+        (vec, perms), sc, depth = tex[1], f32(tex[2]), tex[3]
+        return scale(scale(v3(1, 1, 1), f32(0.5)), f32(1) + np.sin(sc * p[2] + f32(10) * perlin_turb(vec, perms, p, depth)))
+    img = tex[1]
+    h, w = img.shape[0], img.shape[1]
+    uc = _clamp(f32(u), f32(0), f32(1))
+    vc = f32(1) - _clamp(f32(v), f32(0), f32(1))
+    i, j = _as_u32(uc * f32(w)), _as_u32(vc * f32(h))
+    i, j = min(i, w - 1), min(j, h - 1)
+    cs = f32(1.0) / f32(255.0)
+    px = img[j, i]
+    return (f32(px[0]) * cs, f32(px[1]) * cs, f32(px[2]) * cs)
+
+
+def _random_in_unit_sphere(rnd):  # vec3.rs:223-231
+    while True:
+        p = (_stream_randrange(rnd, -1, 1), _stream_randrange(rnd, -1, 1), _stream_randrange(rnd, -1, 1))
+        if dot(p, p) >= f32(1):
+            continue
+        return p
+
+
+def _random_cosine_direction(rnd):  # vec3.rs:257-266
+    r1, r2 = rnd(), rnd()
+    z = np.sqrt(f32(1) - r2)
+    phi = TAU * r1
+    return (np.cos(phi) * np.sqrt(r2), np.sin(phi) * np.sqrt(r2), z)
+
+
+def _onb(n):  # vec3.rs:197-219
+    w = normalize(n)
+    a = v3(0, 1, 0) if abs(w[0]) > f32(0.9) else v3(1, 0, 0)
+    v = normalize(cross(w, a))
+    u = cross(w, v)
+    return u, v, w
+
+
+def _mul(a, b):
+    return (a[0] * b[0], a[1] * b[1], a[2] * b[2])
+
+
+def ray_color(objects, materials, light, background, r, depth, bounce, key):
+    """render.rs:15-41.  light = (x0, x1, z0, z1, k) of a bare XZRect passed as `lights`, or None for anything
+    else (pdf 0, sample (1,0,0): collider.rs:714-725).  key = (seed, pixel, sample)."""
+    if depth <= 0:
+        return v3(0, 0, 0)
+    rnd = PathStream(key[0], key[1], key[2], bounce)
+    rec = scene_intersect(objects, r, f32(0.001), F32_MAX, rnd)
+    if rec is None:
+        return v3(*background)
+    m = materials[rec.prim]
+    kind = m[0]
+    emitted = texture_color(m[1], rec.u, rec.v, rec.p) if kind == "emissive" else v3(0, 0, 0)  # material.rs:176-181
+    # scatter, material.rs:85-169: the scattered ray is overwritten at render.rs:32, so of each variant only the
+    # return value and the attenuation matter, and only the draws that can change those are taken
+    if kind == "lambertian":
+        attenuation = texture_color(m[1], rec.u, rec.v, rec.p)
+    elif kind == "glossy":
+        ud = normalize(r.d)
+        reflected = sub(ud, scale(scale(rec.n, f32(2)), dot(ud, rec.n)))  # vec3.rs:268-270: v - n * 2 * dot(v, n)
+        sd = add(reflected, scale(_random_in_unit_sphere(rnd), f32(m[2])))
+        attenuation = v3(*m[1])
+        if not (dot(sd, rec.n) > f32(0)):
+            return emitted
+    elif kind == "dielectric":
+        attenuation = v3(1, 1, 1)
+    elif kind == "isotropic":
+        attenuation = texture_color(m[1], rec.u, rec.v, rec.p)
+    else:
+        return emitted
+    # render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal (pdf.rs:33-53)
+    u, v, w = _onb(rec.n)
+    if rnd() < f32(0.5):
+        if light is not None:
+            x = _stream_randrange(rnd, light[0], light[1])
+            z = _stream_randrange(rnd, light[2], light[3])
+            direction = sub((x, f32(light[4]), z), rec.p)  # collider.rs:400-403
+        else:
+            direction = v3(1, 0, 0)
+    else:
+        cd = _random_cosine_direction(rnd)
+        direction = add(add(scale(u, cd[0]), scale(v, cd[1])), scale(w, cd[2]))
+    cosin = dot(normalize(direction), w)
+    cos_pdf = f32(0) if cosin <= f32(0) else cosin / PI
+    light_pdf = xzrect_pdf_value(light[0], light[1], light[2], light[3], light[4], rec.p, direction) if light is not None else f32(0)
+    with np.errstate(all="ignore"):
+        pdf_val = f32(0.5) * light_pdf + f32(0.5) * cos_pdf
+        sp = f32(0)  # material.rs:170-175
+        if kind == "lambertian":
+            cs = dot(rec.n, normalize(direction))
+            sp = f32(0) if cs < f32(0) else cs / PI
+        li = ray_color(objects, materials, light, background, Ray(rec.p, direction, r.tm), depth - 1, bounce + 1, key)
+        return add(emitted, div(_mul(scale(attenuation, sp), li), pdf_val))
+
+
+def sample_pixel(objects, materials, light, background, cam, W, H, i, row, sample, max_depth, seed):
+    """One sample of render.rs:95-100 for column i of image row `row` (0 = top) → its radiance."""
+    j = H - 1 - row
+    key = (seed, row * W + i, sample)
+    rnd = PathStream(seed, key[1], sample, CAMERA_BOUNCE)
+    u = (f32(i) + rnd()) / (f32(W) - f32(1))
+    v = (f32(j) + rnd()) / (f32(H) - f32(1))
+    lens = (f32(0), f32(0))
+    if cam.lens_radius != f32(0):  # vec3.rs:247-255; with aperture 0 the sample is multiplied by zero: not drawn
+        while True:
+            lens = (_stream_randrange(rnd, -1, 1), _stream_randrange(rnd, -1, 1))
+            if lens[0] * lens[0] + lens[1] * lens[1] + f32(0) >= f32(1):
+                continue
+            break
+    tm = _stream_randrange(rnd, cam.t_open, cam.t_close)
+    r = cam.ray_through(u, v, lens, tm)
+    return ray_color(objects, materials, light, background, r, max_depth, 0, key)

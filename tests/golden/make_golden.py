@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates the golden primary-hit fixtures under tests/golden/ with oracle/pyoracle.py.
+"""Generates the golden fixtures (primary hits, Perlin samples, whole paths) under tests/golden/ with oracle/pyoracle.py.
 
     python tests/golden/make_golden.py [scene ...]
 
@@ -65,10 +65,22 @@ def make_perlin():
     print("perlin: 128 points")
 
 
+def make_paths():
+    """Whole paths: the radiance of every sample of a small render of tests/golden_paths.py's scene (all material and
+    texture kinds, a medium, a moving sphere, a thin lens), by pyoracle's restatement of ray_color."""
+    import golden_paths as GP
+    t0 = time.time()
+    samples = GP.render_py()
+    np.savez_compressed(os.path.join(HERE, "paths_box.npz"), samples=samples, **{k: np.asarray(v) for k, v in GP.RENDER.items()})
+    print(f"paths_box: {samples.shape[0] * samples.shape[1] * samples.shape[2]} samples, mean {np.nanmean(samples):.4f}, {time.time() - t0:.1f} s")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(G.SCENES) + ["perlin"]
+    names = sys.argv[1:] or list(G.SCENES) + ["perlin", "paths"]
     for nm in names:
         if nm == "perlin":
             make_perlin()
+        elif nm == "paths":
+            make_paths()
         else:
             make_scene(nm)

@@ -265,6 +265,20 @@ def test_final_scene_render_matches_oracle(gpu_ctx):
     assert_render_parity(got, want, min_close=0.97)
 
 
+def test_paths_match_the_numpy_restatement(gpu_ctx):
+    """The whole-path fixture written by the numpy restatement of ray_color (tests/golden/paths_box.npz: every material
+    and texture kind, a medium, a moving sphere, a thin lens), sample by sample, through both kernel organisations."""
+    from test_golden_cpu import _paths_fixture, compare_samples
+    GP, gold = _paths_fixture()
+    b, flat = GP.build_host()
+    gpu_ctx.upload(flat)
+    R = GP.RENDER
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT):
+        got = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"],
+                                                flags=flags))["slice_sums"]
+        compare_samples(got, gold, 0.985)
+
+
 PRESETS = ["default_scene", "random_spheres", "random_moving_spheres", "two_spheres", "two_perlin_spheres", "earth", "rect_light",
            "cornell_box", "cornell_smoke", "cornell_pedestal", "final_scene"]
 
