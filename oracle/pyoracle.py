@@ -560,11 +560,21 @@ def perlin_tables(rng):
     return vec, perms
 
 
+def _as_isize(x):  # Rust `as isize` (64-bit): NaN → 0, saturating
+    if x != x:
+        return 0
+    if x >= 9.2233720368547758e18:
+        return (1 << 63) - 1
+    if x <= -9.2233720368547758e18:
+        return -(1 << 63)
+    return int(x)
+
+
 def perlin_noise(vec, perms, p):  # perlin.rs:47-86
     p = v3(*p)
     fl = [np.floor(c) for c in p]
     u, v, w = p[0] - fl[0], p[1] - fl[1], p[2] - fl[2]
-    i, j, k = int(fl[0]), int(fl[1]), int(fl[2])
+    i, j, k = _as_isize(fl[0]), _as_isize(fl[1]), _as_isize(fl[2])
     uu = u * u * (f32(3) - f32(2) * u)
     vv = v * v * (f32(3) - f32(2) * v)
     ww = w * w * (f32(3) - f32(2) * w)

@@ -71,8 +71,11 @@ def make_paths():
     import golden_paths as GP
     t0 = time.time()
     samples = GP.render_py()
-    np.savez_compressed(os.path.join(HERE, "paths_box.npz"), samples=samples, **{k: np.asarray(v) for k, v in GP.RENDER.items()})
-    print(f"paths_box: {samples.shape[0] * samples.shape[1] * samples.shape[2]} samples, mean {np.nanmean(samples):.4f}, {time.time() - t0:.1f} s")
+    nolight = GP.render_py(light=False)  # empty `lights`: the 0/0 = NaN samples of render.rs:34
+    np.savez_compressed(os.path.join(HERE, "paths_box.npz"), samples=samples, samples_nolight=nolight,
+                        **{k: np.asarray(v) for k, v in GP.RENDER.items()})
+    print(f"paths_box: {samples.shape[0] * samples.shape[1] * samples.shape[2]} samples, mean {np.nanmean(samples):.4f}; without a light "
+          f"{np.isnan(nolight).any(axis=-1).mean():.2f} of the samples are NaN; {time.time() - t0:.1f} s")
 
 
 if __name__ == "__main__":

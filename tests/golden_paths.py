@@ -41,7 +41,9 @@ def build_py():
     return objs, P.materials_by_prim(objs), cam
 
 
-def build_host():
+def build_host(light=True):
+    """light=False: an empty list is passed as `lights` (as random_spheres does, main.rs:111): its pdf is 0 and its
+    sample (1,0,0), so many samples are 0/0 = NaN (render.rs:34)."""
     import rust_raytracer_amd  # noqa: F401
     from rust_raytracer_amd import host
     b = host.SceneBuilder(SEED)
@@ -50,8 +52,8 @@ def build_host():
     img = b.lambertian(b.load_image_rgb8(IMAGE))
     small = [b.sphere((120 + 60 * i, 60 + 25 * i, 120 + 50 * (i % 3)), 28.0, img if i == 2 else lam((0.2 + 0.15 * i, 0.6, 0.9 - 0.15 * i)))
              for i in range(5)]
-    light = b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0)))
-    for g in [b.yzrect(0, 555, 0, 555, 555, lam(GREEN)), b.yzrect(0, 555, 0, 555, 0, lam(RED)), light,
+    lamp = b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0)))
+    for g in [b.yzrect(0, 555, 0, 555, 555, lam(GREEN)), b.yzrect(0, 555, 0, 555, 0, lam(RED)), lamp,
               b.xzrect(0, 555, 0, 555, 0, b.lambertian(b.checkered((0.2, 0.3, 0.1), (0.9, 0.9, 0.9)))),
               b.xzrect(0, 555, 0, 555, 555, lam(WHITE)), b.xyrect(0, 555, 0, 555, 555, noise),
               b.instance_translation(b.instance_rotation(b.cuboid((0, 0, 0), (165, 330, 165), lam(WHITE)), 1, 15.0), (265, 0, 295)),
@@ -60,21 +62,25 @@ def build_host():
               b.moving_sphere((100, 400, 200), (130, 400, 200), 0.0, 1.0, 50.0, lam((0.7, 0.3, 0.1))),
               b.bvh_node(small, 0.0, 1.0)]:
         b.add(g)
-    b.set_lights(b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0))))
+    b.set_lights(b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0))) if light else b.collider_list([]))
     b.set_camera(CAM["look_from"], CAM["look_at"], CAM["vup"], CAM["vfov"], CAM["aperture"], CAM["focus_dist"], CAM["aspect"], 0.0, 1.0)
     b.set_background(BACKGROUND)
     return b, b.flatten()
 
 
-def render_py():
+NOLIGHT = dict(W=16, H=12, spp=4)  # the second, smaller render: same scene, empty `lights`
+
+
+def render_py(light=True):
     """→ float32 [spp, H, W, 3]: the radiance of every sample, laid out like the per-slice sums of a render with one
     sample per slice."""
     import pyoracle as P
     objs, mats, cam = build_py()
-    W, H, spp = RENDER["W"], RENDER["H"], RENDER["spp"]
+    W, H, spp = (RENDER if light else NOLIGHT)["W"], (RENDER if light else NOLIGHT)["H"], (RENDER if light else NOLIGHT)["spp"]
     out = np.zeros((spp, H, W, 3), dtype=np.float32)
     for s in range(spp):
         for row in range(H):
             for i in range(W):
-                out[s, row, i] = P.sample_pixel(objs, mats, LIGHT, BACKGROUND, cam, W, H, i, row, s, RENDER["max_depth"], RENDER["seed"])
+                out[s, row, i] = P.sample_pixel(objs, mats, LIGHT if light else None, BACKGROUND, cam, W, H, i, row, s,
+                                                RENDER["max_depth"], RENDER["seed"])
     return out

@@ -53,6 +53,11 @@ def _paths_fixture():
     return GP, fx["samples"]
 
 
+def _nolight_fixture():
+    import golden_paths as GP
+    return GP, np.load(os.path.join(G.GOLDEN_DIR, "paths_box.npz"))["samples_nolight"]
+
+
 def compare_samples(got, gold, min_close):
     """Per-sample radiances against the numpy restatement's.  Both follow the Rust text operation by operation and
     share their random numbers; they differ where sin/cos/log10/acos/atan2 of two math libraries differ in the last
@@ -77,6 +82,18 @@ def test_cpp_oracle_paths_match_the_numpy_restatement(built):
     both = ~np.isnan(got) & ~np.isnan(gold)
     assert (got[both] == gold[both]).mean() > 0.9          # most samples never meet a library difference: bit-identical
     assert (gold[both] != 0).mean() > 0.5
+
+
+def test_cpp_oracle_nan_samples_match_the_numpy_restatement(built):
+    """The same scene with an empty list as `lights` (pdf 0, sample (1,0,0), collider.rs:714-725): which samples come out
+    as 0/0 = NaN (render.rs:34) and what the others are."""
+    GP, gold = _nolight_fixture()
+    b, flat = GP.build_host(light=False)
+    R, N = GP.RENDER, GP.NOLIGHT
+    p = O.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    got = O.render(flat, p, n_threads=4)["slice_sums"]
+    assert 0.1 < np.isnan(gold).mean() < 0.9
+    compare_samples(got, gold, 0.99)
 
 
 def test_paths_fixture_is_reproducible():

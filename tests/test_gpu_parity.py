@@ -277,6 +277,13 @@ def test_paths_match_the_numpy_restatement(gpu_ctx):
         got = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"],
                                                 flags=flags))["slice_sums"]
         compare_samples(got, gold, 0.985)
+    from test_golden_cpu import _nolight_fixture
+    GP, gold = _nolight_fixture()  # an empty list as `lights`: the NaN samples of render.rs:34
+    b, flat = GP.build_host(light=False)
+    gpu_ctx.upload(flat)
+    N = GP.NOLIGHT
+    got = gpu_ctx.render(device.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"]))["slice_sums"]
+    compare_samples(got, gold, 0.985)
 
 
 PRESETS = ["default_scene", "random_spheres", "random_moving_spheres", "two_spheres", "two_perlin_spheres", "earth", "rect_light",
