@@ -444,6 +444,32 @@ def test_full_size_cornell_configuration(gpu_ctx):
     assert rmse < 0.35, rmse
 
 
+@pytest.mark.parametrize("name,depth", [("suzanne", 100), ("final", 50)])
+def test_full_size_bvh_configurations(gpu_ctx, name, depth):
+    """The BVH configurations at their full image size and 1000 spp (several batches of the wavefront pipeline, two
+    workspaces in turns), through properties that do not need the oracle: every sample is traced, reruns are identical,
+    two halves of the slices rendered on their own add up to the whole render bit for bit, and the image energy equals
+    that of a render with other random numbers within Monte-Carlo error."""
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=8, max_depth=depth, seed=1)
+    whole = gpu_ctx.render(device.make_params(800, 800, 1000, **kw), slice_sums=False)
+    assert whole["counters"]["samples"] == 800 * 800 * 1000
+    assert 1.5 < whole["counters"]["rays"] / whole["counters"]["samples"] < 5.0
+    assert np.isfinite(whole["linear"]).all() and whole["rgb8"].max() > 100
+    again = gpu_ctx.render(device.make_params(800, 800, 1000, **kw), slice_sums=False)
+    assert np.array_equal(whole["rgb8"], again["rgb8"]) and np.array_equal(whole["linear"], again["linear"])
+    lo = gpu_ctx.render(device.make_params(800, 800, 1000, slice_begin=0, slice_end=4, **kw), slice_sums=False)
+    hi = gpu_ctx.render(device.make_params(800, 800, 1000, slice_begin=4, slice_end=8, **kw), slice_sums=False)
+    assert lo["counters"]["samples"] + hi["counters"]["samples"] == whole["counters"]["samples"]
+    assert lo["counters"]["rays"] + hi["counters"]["rays"] == whole["counters"]["rays"]
+    assert np.allclose(lo["linear"] + hi["linear"], whole["linear"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(lo["resolved"] + hi["resolved"], whole["resolved"], rtol=1e-6, atol=1e-6)
+    other = gpu_ctx.render(device.make_params(800, 800, 64, n_slices=8, max_depth=depth, seed=99), slice_sums=False)
+    m_whole, m_other = whole["linear"].mean() / 1000.0, other["linear"].mean() / 64.0
+    assert abs(m_whole - m_other) < 0.02 * m_other, (m_whole, m_other)
+
+
 @pytest.mark.parametrize("name,side,spp,depth", [("cornell", 96, 512, 50), ("suzanne", 64, 256, 50), ("final", 48, 256, 30)])
 def test_converged_images_agree_within_rmse(gpu_ctx, name, side, spp, depth):
     """Per-channel RMSE of the displayed-range linear radiance (mean sample value clamped to [0, 1], as
