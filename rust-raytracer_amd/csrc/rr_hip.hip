@@ -35,6 +35,7 @@ struct RenderArgs {
     uint32_t max_depth;
     uint32_t sample_offset;
     uint64_t seed;
+    unsigned long long* next_item;  // the first work item no wave has claimed yet (zero at launch)
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -57,14 +58,19 @@ __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long
     }
 }
 
+#ifndef RR_RENDER_CHUNK
+#define RR_RENDER_CHUNK 64u  // work items a wave claims at a time
+#endif
 template <bool COUNT, bool VEC>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
                                                 unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
-    const uint64_t item_stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-    uint64_t q = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    // Work items (slice, pixel) are handed out dynamically, a chunk per wave and claim: pixels differ in how long their
+    // paths are, and with a fixed share per lane the waves over cheap regions would sit idle at the end (measured: a
+    // fifth of the wave slots of the Cornell box render).  A chunk is 64 consecutive items, one 8x8 tile of one slice.
+    uint64_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
 
     Counts cnt = {0, 0, 0, 0, 0, 0, 0};
     bool have_item = false, path_active = false;
@@ -79,52 +85,62 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
     // flow, where its program counter, op words and branches stay on the scalar unit.
     bool lane_done = false;
     for (;;) {
-        // ---- refill: lanes whose path ended take their next sample, or their next work item
-        if (!path_active && !lane_done) {
-            for (;;) {
-                if (!have_item) {
-                    bool found = false;
-                    while (q < a.n_items) {
-                        const uint32_t r = static_cast<uint32_t>(q % a.padded_pixels);
-                        sl = static_cast<uint32_t>(q / a.padded_pixels);
-                        const uint32_t tile = r >> 6, within = r & 63u;
-                        px = (tile % a.tiles_x) * 8u + (within & 7u);
-                        py = (tile / a.tiles_x) * 8u + (within >> 3);
-                        if (px < a.width && py < a.height) {
-                            found = true;
-                            break;
-                        }
-                        q += item_stride;
-                    }
-                    if (!found) {
-                        lane_done = true;
-                        break;
-                    }
+        // ---- lanes whose path ended: pixel_color of render.rs:93-100 is complete for this slice once the item's samples are through
+        auto finish_item = [&]() {
+            float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.height + py) * a.width + px) * 3u;
+            dst[0] = acc.x;
+            dst[1] = acc.y;
+            dst[2] = acc.z;
+            have_item = false;
+        };
+        if (!path_active && have_item && s == a.spt) finish_item();
+        // ---- lanes without an item take the next unclaimed ones
+        for (;;) {
+            const bool need = !path_active && !have_item && !lane_done;
+            const uint64_t mask = __ballot(need);
+            if (mask == 0) break;
+            if (chunk_pos == chunk_end) {
+                unsigned long long base = 0;
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(a.next_item, static_cast<unsigned long long>(RR_RENDER_CHUNK));
+                base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
+                       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+                chunk_pos = min(static_cast<uint64_t>(base), a.n_items);
+                chunk_end = min(static_cast<uint64_t>(base) + RR_RENDER_CHUNK, a.n_items);
+            }
+            if (chunk_pos == chunk_end) {  // the counter only grows: nothing is left for anyone
+                if (need) lane_done = true;
+                break;
+            }
+            const uint32_t take = static_cast<uint32_t>(min(static_cast<uint64_t>(__popcll(mask)), chunk_end - chunk_pos));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            if (need && rank < take) {
+                const uint64_t q = chunk_pos + rank;
+                const uint32_t r = static_cast<uint32_t>(q % a.padded_pixels);
+                sl = static_cast<uint32_t>(q / a.padded_pixels);
+                const uint32_t tile = r >> 6, within = r & 63u;
+                px = (tile % a.tiles_x) * 8u + (within & 7u);
+                py = (tile / a.tiles_x) * 8u + (within >> 3);
+                if (px < a.width && py < a.height) {  // (items of the padding around the image are dropped)
                     have_item = true;
                     s = 0;
                     acc = mk3(0.f, 0.f, 0.f);
                     pixel_key = py * a.width + px;
+                    if (a.spt == 0) finish_item();
                 }
-                if (s != a.spt) break;
-                // pixel_color of render.rs:93-100 is complete for this slice
-                float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.height + py) * a.width + px) * 3u;
-                dst[0] = acc.x;
-                dst[1] = acc.y;
-                dst[2] = acc.z;
-                have_item = false;
-                q += item_stride;
             }
-            if (!lane_done) {
-                sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
-                Rng g;
-                g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
-                camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
-                thr = mk3(1.f, 1.f, 1.f);
-                depth_left = a.max_depth;
-                bounce = 0;
-                path_active = true;
-                cnt.samples++;
-            }
+            chunk_pos += take;
+        }
+        // ---- lanes with an item and no path take their next sample
+        if (!path_active && have_item) {
+            sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
+            Rng g;
+            g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
+            camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
+            thr = mk3(1.f, 1.f, 1.f);
+            depth_left = a.max_depth;
+            bounce = 0;
+            path_active = true;
+            cnt.samples++;
         }
         if (!__any(path_active)) break;
         // ---- one ray_color call (render.rs:15-41) for every lane that has a path
@@ -279,6 +295,7 @@ struct rr_context {
     void* wf_mem = nullptr;
     size_t wf_bytes = 0;
     uint32_t* wf_host_count = nullptr;
+    unsigned long long* next_item = nullptr;  // k_render's work-item counter (device memory)
     hipStream_t wf_aux = nullptr;                 // k_wf_finish and the accumulation of a batch run here, beside the next batch
     hipEvent_t wf_ev_main[2] = {nullptr, nullptr};  // per workspace: the batch's bounce loop is enqueued
     hipEvent_t wf_ev_aux[2] = {nullptr, nullptr};   // per workspace: the batch is accumulated, the workspace is free
@@ -892,6 +909,7 @@ int rr_context_destroy(rr_context* ctx) {
     ctx->scene_mem.release();
     if (ctx->wf_mem) (void)hipFree(ctx->wf_mem);
     if (ctx->wf_host_count) (void)hipHostFree(ctx->wf_host_count);
+    if (ctx->next_item) (void)hipFree(ctx->next_item);
     if (ctx->wf_aux) (void)hipStreamDestroy(ctx->wf_aux);
     for (int k = 0; k < 2; ++k) {
         if (ctx->wf_ev_main[k]) (void)hipEventDestroy(ctx->wf_ev_main[k]);
@@ -1295,9 +1313,12 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     // Slices are rendered in groups so that one launch stays within about 2^31 samples.
     const uint64_t samples_per_slice = static_cast<uint64_t>(p->width) * p->height * std::max(spt, 1u);
     uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (1ull << 31) / samples_per_slice));
+    if (!ctx->next_item) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->next_item), sizeof(unsigned long long)));
+    a.next_item = ctx->next_item;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     for (uint32_t s0 = 0; s0 < n_sl; s0 += group) {
         const uint32_t cnt = std::min(group, n_sl - s0);
+        HIP_TRY(hipMemsetAsync(ctx->next_item, 0, sizeof(unsigned long long), stream));
         a.n_items = static_cast<uint64_t>(cnt) * a.padded_pixels;
         a.slice_first = p->slice_begin + s0;
         a.slice_out = s0;
