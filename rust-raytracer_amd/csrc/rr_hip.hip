@@ -863,6 +863,53 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     return RR_OK;
 }
 
+// The persistent renderer at path granularity (scenes without BVH subtrees): batches of samples of every slot, each one
+// launch of k_wf_paths that leaves every sample's value in the workspace, and the in-order accumulation of the batch.
+int render_paths(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream) {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
+    size_t cap = budget;
+    if (const char* env = std::getenv("RR_WF_WORKSPACE_BYTES")) cap = std::max<size_t>(1, std::strtoull(env, nullptr, 10));  // for tests
+    const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, std::max<uint64_t>(1, cap / (16u * static_cast<uint64_t>(a.n_slots))));
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(most, std::max(a.spt, 1u)));
+    const size_t need = static_cast<size_t>(a.n_slots) * batch * 16u + 256u;
+    if (need > ctx->wf_bytes) {
+        if (ctx->wf_mem) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(ctx->wf_mem));
+            ctx->wf_mem = nullptr;
+            ctx->wf_bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&ctx->wf_mem, need));
+        ctx->wf_bytes = need;
+    }
+    if (!ctx->next_item) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->next_item), sizeof(unsigned long long)));
+    WfState st{};
+    st.thr = static_cast<float4*>(ctx->wf_mem);
+    using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
+    const PathsKernel kernel = ctx->prog_vector_ops ? (count ? k_wf_paths<true, true> : k_wf_paths<false, true>)
+                                                    : (count ? k_wf_paths<true, false> : k_wf_paths<false, false>);
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    int grid = 0;
+    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
+    const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
+    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
+        a.s0 = s0;
+        a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        if (a.n_paths != 0) {
+            HIP_TRY(hipMemsetAsync(ctx->next_item, 0, sizeof(unsigned long long), stream));
+            const uint32_t g = std::min<uint32_t>(static_cast<uint32_t>(grid), (a.n_paths + 255u) / 256u);
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, reinterpret_cast<unsigned int*>(ctx->next_item), counters);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
+        HIP_TRY(hipGetLastError());
+        if (a.spt == 0) break;
+    }
+    return RR_OK;
+}
+
 }  // namespace
 
 // ================================================================== C ABI
@@ -1267,7 +1314,9 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     if ((p->flags & RR_FLAG_PERSISTENT) && (p->flags & RR_FLAG_WAVEFRONT))
         return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT and RR_FLAG_WAVEFRONT exclude each other");
     const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->has_subtrees && !(p->flags & RR_FLAG_PERSISTENT));
-    if (wavefront) {
+    // scenes without BVH subtrees: the persistent kernel at path granularity (k_wf_paths), unless k_render is asked for
+    const bool paths = !wavefront && !(p->flags & RR_FLAG_PERSISTENT);
+    if (wavefront || paths) {
         const uint64_t n_pixels = static_cast<uint64_t>(p->width) * p->height;
         if (n_pixels > (1ull << 30)) return fail(RR_E_LIMIT, "rr_render_device: more than 2^30 pixels in one wavefront pass");
         WfArgs w{};
@@ -1286,7 +1335,8 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.slice_first = p->slice_begin + s0;
             w.slice_out = s0;
-            if (int rc = render_wavefront(ctx, w, count, p->flags, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
+            if (int rc = paths ? render_paths(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream)
+                               : render_wavefront(ctx, w, count, p->flags, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
                 return rc;
         }
         HIP_TRY(hipEventRecord(ctx->ev1, stream));

@@ -114,6 +114,94 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
     dst[0] = acc.x, dst[1] = acc.y, dst[2] = acc.z;
 }
 
+#ifndef RR_PATHS_CHUNK
+#define RR_PATHS_CHUNK 512u  // paths a wave claims at a time
+#endif
+// The persistent form of the path tracer at the granularity of single paths: a lane follows one path from its camera
+// ray to its end like k_render's, but what it claims next is a path, not the rest of a pixel's samples, and it leaves
+// the sample's value behind for k_wf_accumulate to add up in sample order (render.rs:93-100).  A (slice, pixel) item
+// of k_render is spt samples that one lane must take one after the other; with a few items per lane the waves end
+// at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
+// A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
+// hands them to its lanes as their paths end.
+template <bool COUNT, bool VEC>
+__global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc, WfArgs a, float4* __restrict__ values,
+                                                                              unsigned int* next_path, unsigned long long* counters) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t* stk = lds_stack + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
+    bool exhausted = a.n_paths == 0;        // wave-uniform: no unclaimed paths are left for anyone
+    bool path_active = false;
+    uint32_t p = 0, pixel = 0, sample = 0, depth_left = 0, bounce = 0;
+    f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(0.f, 0.f, 0.f), thr = mk3(1.f, 1.f, 1.f);
+    float time = 0.f;
+    // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
+    // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
+    for (;;) {
+        const uint64_t idle = __ballot(!path_active);
+        if (!exhausted && idle != 0) {
+            if (chunk_pos == chunk_end) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(next_path, RR_PATHS_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                chunk_pos = min(base, a.n_paths);
+                chunk_end = min(base + RR_PATHS_CHUNK, a.n_paths);
+            }
+            const uint32_t take = min(static_cast<uint32_t>(__popcll(idle)), chunk_end - chunk_pos);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+            if (!path_active && rank < take) {
+                p = chunk_pos + rank;
+                wf_path_key(a, p, pixel, sample);
+                Rng g;
+                g.start(a.seed, pixel, sample, CAMERA_BOUNCE);
+                camera_ray(sc, a.width, a.height, pixel % a.width, a.height - 1u - pixel / a.width, g, ro, rd, time);
+                thr = mk3(1.f, 1.f, 1.f);
+                depth_left = a.max_depth;
+                bounce = 0;
+                path_active = true;
+                cnt.samples++;
+            }
+            chunk_pos += take;
+            exhausted = chunk_pos == chunk_end && chunk_end == a.n_paths;  // the counter only grows
+        }
+        if (!__any(path_active)) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one ray_color call (render.rs:15-41) for every lane that has a path
+        const bool run = path_active && depth_left != 0;
+        if (run) cnt.rays++;
+        Rng g;
+        g.start(a.seed, pixel, sample, bounce);
+        float t;
+        uint32_t ref;
+        traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+        f3 terminal = mk3(0.f, 0.f, 0.f);
+        bool go_on = false;
+        if (run) {
+            Bounce b;
+            go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
+            if (go_on) {
+                ro = b.o;
+                rd = b.d;
+                thr = thr * b.weight;
+                depth_left -= 1;
+                bounce += 1;
+            } else {
+                terminal = b.terminal;
+            }
+        }
+        if (path_active && !go_on) {
+            const f3 c = thr * terminal;  // the sample's value (render.rs:99 adds it to the pixel)
+            values[p] = make_float4(c.x, c.y, c.z, 0.f);
+            path_active = false;
+        }
+    }
+    flush_counts(cnt, counters);
+}
+
 // Providers for the traversal machine: what it rarely needs is read from the slot when it does.
 struct WfWorld {
     const WfState& st;

@@ -389,6 +389,30 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
         assert one["counters"] == two["counters"]
 
 
+def test_path_granular_kernel_equals_item_granular_kernel(gpu_ctx, monkeypatch):
+    """Scenes without BVH subtrees render with the persistent kernel that hands out single paths and adds the samples
+    up afterwards (the default) or with the one whose lanes take whole (slice, pixel) items (RR_FLAG_PERSISTENT): same
+    bits, also over many small batches, slice ranges, sample offsets, no samples at all and depth 0."""
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=3, max_depth=30, seed=19)
+    for extra in (dict(), dict(flags=abi.FLAG_COUNTERS), dict(slice_begin=1, slice_end=3), dict(sample_offset=77), dict(max_depth=0)):
+        args = dict(kw)
+        args.update(extra)
+        flags = args.pop("flags", 0)
+        one = gpu_ctx.render(device.make_params(53, 41, 14, flags=abi.FLAG_PERSISTENT | flags, **args))
+        two = gpu_ctx.render(device.make_params(53, 41, 14, flags=flags, **args))
+        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True), extra
+        assert np.array_equal(one["rgb8"], two["rgb8"]) and one["counters"] == two["counters"], extra
+    one = gpu_ctx.render(device.make_params(53, 41, 2, flags=abi.FLAG_PERSISTENT, **kw))  # fewer samples than slices: none are taken
+    two = gpu_ctx.render(device.make_params(53, 41, 2, **kw))
+    assert np.array_equal(one["slice_sums"], two["slice_sums"]) and two["counters"]["samples"] == 0
+    one = gpu_ctx.render(device.make_params(53, 41, 60, flags=abi.FLAG_PERSISTENT, **kw))
+    monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(16 * 3 * 53 * 41 * 3))  # three samples per slot and batch: 7 batches of 20
+    two = gpu_ctx.render(device.make_params(53, 41, 60, **kw))
+    assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True) and one["counters"] == two["counters"]
+
+
 @pytest.mark.parametrize("name,side,spp", [("suzanne", 640, 96), ("final", 512, 136)])
 def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp):
     """A batch of more than 2^25 paths, deep enough for many lanes of the kernel that finishes the paths to be parked
