@@ -226,10 +226,13 @@ typedef struct rr_render_params {
 
 #define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests; this build of the kernels makes
                                every BVH visit the reference makes, in its order (slower, same image) */
-/* The library renders with one of two kernel organisations that produce the same bits: a single
- * persistent kernel (a lane follows its path from camera ray to termination), used for scenes
- * without BVH nodes, and a wavefront pipeline (traversal and shading kernels over a compacted
- * queue of live paths), used for scenes with them.  These flags override the choice.       */
+/* The library renders with one of three kernel organisations that produce the same bits.  Scenes
+ * without BVH nodes: a persistent kernel whose lanes follow single paths from camera ray to
+ * termination and leave the sample values for an in-order accumulation.  Scenes with BVH nodes: a
+ * wavefront pipeline (traversal and shading kernels over a compacted queue of live paths for the camera
+ * rays, then a persistent kernel for the rest of every path).  RR_FLAG_PERSISTENT selects a third, a
+ * persistent kernel whose lanes own a (slice, pixel) at a time and add its samples themselves;
+ * RR_FLAG_WAVEFRONT forces the pipeline.                                                          */
 #define RR_FLAG_PERSISTENT 2u
 #define RR_FLAG_WAVEFRONT 4u
 /* After its first bounces the wavefront pipeline hands the paths still alive to a kernel that runs each of

@@ -7,7 +7,7 @@
   <tag>_pmc_traffic.json              HBM bytes per sample and workload (read by bench.py for roofline.traffic)
 
 Only the kernels of the timed step count: bench.py's instrumented pass afterwards is cut off at the first dispatch of a
-counting kernel (k_render<true> / k_wf_traverse<true> / k_wf_finish<true>).
+counting kernel (k_render<true> / k_wf_paths<true> / k_wf_traverse<true> / k_wf_finish<true>).
 
 usage: python profiles/summarize.py <tag> <workload>
 """
@@ -30,6 +30,10 @@ def short(name):
         return "k_render<false>"
     if "k_render<true" in name:
         return "k_render<true>"
+    if "k_wf_paths<false" in name:
+        return "k_wf_paths<false>"
+    if "k_wf_paths<true" in name:
+        return "k_wf_paths<true>"
     for k in ("k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_finish<false>", "k_wf_finish<true>", "k_wf_shade",
               "k_wf_init", "k_wf_accumulate", "k_resolve", "k_cast_u8"):
         if k in name:
@@ -44,7 +48,7 @@ def newest(pattern):
 
 
 def counting(name):
-    return "k_render<true" in name or "k_wf_traverse<true>" in name or "k_wf_finish<true>" in name
+    return "k_render<true" in name or "k_wf_paths<true" in name or "k_wf_traverse<true>" in name or "k_wf_finish<true>" in name
 
 
 def last_json_line(path):
