@@ -201,7 +201,7 @@ def main():
         # scenes without BVH nodes are one launch of the persistent kernel; scenes with them go through the
         # wavefront pipeline, whose launches (two per bounce) the HIP events bracket as a whole
         kernel_name = ("wavefront pipeline: k_wf_init + k_wf_traverse<false> + k_wf_shade (camera rays) + k_wf_finish<false> + k_wf_accumulate"
-                       if info["wavefront"] else "k_wf_paths<false, false> (persistent kernel at path granularity, counters off, no per-lane record fetches) + k_wf_accumulate")
+                       if info["wavefront"] else "k_wf_paths<false, ...> (persistent kernel at path granularity, counters off) + k_wf_accumulate")
         alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes kept under profiles/ (bytes per sample there, times this launch's samples)

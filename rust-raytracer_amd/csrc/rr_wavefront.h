@@ -114,6 +114,15 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
     dst[0] = acc.x, dst[1] = acc.y, dst[2] = acc.z;
 }
 
+#ifndef RR_WF_FINISH_PARK_BELOW
+#define RR_WF_FINISH_PARK_BELOW 12  // lanes still descending in a subtree are parked once fewer than this many are left
+#endif
+#ifndef RR_WF_FINISH_PARK_MIN_STEPS
+#define RR_WF_FINISH_PARK_MIN_STEPS 4  // machine steps a visit of a subtree takes at least, so that parked lanes get on
+#endif
+#ifndef RR_WF_FINISH_PARK_MIN_FRESH
+#define RR_WF_FINISH_PARK_MIN_FRESH 8  // with the queue drained and fewer lanes than this starting a ray, nothing is parked
+#endif
 #ifndef RR_PATHS_CHUNK
 #define RR_PATHS_CHUNK 512u  // paths a wave claims at a time
 #endif
@@ -124,7 +133,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-template <bool COUNT, bool VEC>
+template <bool COUNT, bool VEC, bool PARK = false>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -137,6 +146,14 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
     uint32_t p = 0, pixel = 0, sample = 0, depth_left = 0, bounce = 0;
     f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(0.f, 0.f, 0.f), thr = mk3(1.f, 1.f, 1.f);
     float time = 0.f;
+    // PARK (scenes with BVH subtrees): the few lanes with the deepest descents do not hold the wave in a subtree;
+    // they keep their traversal state and come back to it in later turns (traverse_parking)
+    ProgState ps;
+    uint32_t draws = 0;
+    if (PARK) {
+        ps.start(ro, rd, 0.f, 0.f);
+        ps.m.begin(NONE, ro, rd, 0.f, 0.f, NONE);
+    }
     // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
     // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
     for (;;) {
@@ -162,6 +179,10 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
                 bounce = 0;
                 path_active = true;
                 cnt.samples++;
+                if (PARK) {
+                    draws = 0;
+                    ps.start(ro, rd, 0.001f, kF32Max);
+                }
             }
             chunk_pos += take;
             exhausted = chunk_pos == chunk_end && chunk_end == a.n_paths;  // the counter only grows
@@ -172,15 +193,29 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
         }
         // ---- one ray_color call (render.rs:15-41) for every lane that has a path
         const bool run = path_active && depth_left != 0;
-        if (run) cnt.rays++;
+        const bool was_parked = PARK && ps.parked;
+        if (run && !was_parked) cnt.rays++;
         Rng g;
         g.start(a.seed, pixel, sample, bounce);
         float t;
         uint32_t ref;
-        traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+        bool parked = false;
+        if (PARK) {
+            g.n = draws;
+            if (g.n & 3u) g.refill();
+            const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !was_parked)));
+            const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
+            traverse_parking<COUNT>(sc, ro, rd, time, run, ps, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt);
+            draws = g.n;
+            t = ps.tmax;
+            ref = ps.cur;
+            parked = run && ps.parked;
+        } else {
+            traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
+        }
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
-        if (run) {
+        if (run && !parked) {
             Bounce b;
             go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
             if (go_on) {
@@ -189,11 +224,15 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
                 thr = thr * b.weight;
                 depth_left -= 1;
                 bounce += 1;
+                if (PARK) {
+                    draws = 0;
+                    ps.start(ro, rd, 0.001f, kF32Max);
+                }
             } else {
                 terminal = b.terminal;
             }
         }
-        if (path_active && !go_on) {
+        if (path_active && !go_on && !parked) {
             const f3 c = thr * terminal;  // the sample's value (render.rs:99 adds it to the pixel)
             values[p] = make_float4(c.x, c.y, c.z, 0.f);
             path_active = false;
@@ -422,15 +461,6 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 
 #ifndef RR_WF_FINISH_WAVES_PER_SIMD
 #define RR_WF_FINISH_WAVES_PER_SIMD 4
-#endif
-#ifndef RR_WF_FINISH_PARK_BELOW
-#define RR_WF_FINISH_PARK_BELOW 12  // lanes still descending in a subtree are parked once fewer than this many are left
-#endif
-#ifndef RR_WF_FINISH_PARK_MIN_STEPS
-#define RR_WF_FINISH_PARK_MIN_STEPS 4  // machine steps a visit of a subtree takes at least, so that parked lanes get on
-#endif
-#ifndef RR_WF_FINISH_PARK_MIN_FRESH
-#define RR_WF_FINISH_PARK_MIN_FRESH 8  // with the queue drained and fewer lanes than this starting a ray, nothing is parked
 #endif
 
 // The rest of a batch after its first bounces.  With every bounce fewer paths are left, and a bounce costs

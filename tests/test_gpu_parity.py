@@ -364,6 +364,8 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
         assert one["counters"] == two["counters"]
+        auto = gpu_ctx.render(device.make_params(45, 37, 9, flags=extra, **kw))  # whichever organisation the library picks
+        assert np.array_equal(one["slice_sums"], auto["slice_sums"], equal_nan=True) and one["counters"] == auto["counters"]
     # a slice range, a sample offset and zero depth go through the same bookkeeping
     for kw2 in (dict(slice_begin=1, slice_end=3), dict(sample_offset=40), dict(max_depth=0), dict(max_depth=1)):
         args = dict(kw)
@@ -372,6 +374,8 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT, **args))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True), kw2
         assert one["counters"] == two["counters"]
+        auto = gpu_ctx.render(device.make_params(45, 37, 9, **args))
+        assert np.array_equal(one["slice_sums"], auto["slice_sums"], equal_nan=True) and one["counters"] == auto["counters"], kw2
 
 
 def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch):
@@ -383,8 +387,8 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
     kw = dict(n_slices=2, max_depth=40, seed=31)
     one = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_PERSISTENT, **kw))
     monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(80 * 2 * 40 * 32 * 5))  # five samples per slot and batch: 5 batches of 23
-    for extra in (0, abi.FLAG_NO_FINISH_KERNEL):
-        two = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_WAVEFRONT | extra, **kw))
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, 0):
+        two = gpu_ctx.render(device.make_params(40, 32, 46, flags=flags, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert one["counters"] == two["counters"]
 
@@ -422,10 +426,11 @@ def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp
     kw = dict(n_slices=8, max_depth=25, seed=41)
     assert side * side * spp >= 1 << 25
     one = gpu_ctx.render(device.make_params(side, side, spp, flags=abi.FLAG_PERSISTENT, **kw))
-    two = gpu_ctx.render(device.make_params(side, side, spp, flags=abi.FLAG_WAVEFRONT, **kw))
-    assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
-    assert np.array_equal(one["rgb8"], two["rgb8"])
-    assert one["counters"] == two["counters"]
+    for flags in (abi.FLAG_WAVEFRONT, 0):
+        two = gpu_ctx.render(device.make_params(side, side, spp, flags=flags, **kw))
+        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
+        assert np.array_equal(one["rgb8"], two["rgb8"])
+        assert one["counters"] == two["counters"]
 
 
 # --------------------------------------------------- size-independent properties
