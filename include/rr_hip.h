@@ -239,6 +239,8 @@ typedef struct rr_render_params {
  * them to its end; this flag keeps it to bounce-by-bounce launches throughout, which makes the call
  * synchronise with the stream after every bounce from the fourth on (for tests: the result is the same). */
 #define RR_FLAG_NO_FINISH_KERNEL 8u
+/* Forces the path-granular persistent kernel (the default of most scenes) for any scene. */
+#define RR_FLAG_PATHS 16u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */

@@ -22,6 +22,7 @@ FLAG_COUNTERS = 1
 FLAG_PERSISTENT = 2
 FLAG_WAVEFRONT = 4
 FLAG_NO_FINISH_KERNEL = 8
+FLAG_PATHS = 16
 PERLIN_POINTS = 256
 
 

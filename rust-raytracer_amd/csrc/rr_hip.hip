@@ -1321,10 +1321,10 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     const uint32_t n_sl = p->slice_end - p->slice_begin;
     const uint32_t spt = p->samples_per_pixel / p->n_slices;
     const bool count = (p->flags & RR_FLAG_COUNTERS) != 0;
-    if ((p->flags & RR_FLAG_PERSISTENT) && (p->flags & RR_FLAG_WAVEFRONT))
-        return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT and RR_FLAG_WAVEFRONT exclude each other");
+    if (((p->flags & RR_FLAG_PERSISTENT) != 0) + ((p->flags & RR_FLAG_WAVEFRONT) != 0) + ((p->flags & RR_FLAG_PATHS) != 0) > 1)
+        return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT, RR_FLAG_WAVEFRONT and RR_FLAG_PATHS exclude each other");
     // the persistent kernel at path granularity (k_wf_paths) unless the scene is one for the pipeline or a flag asks for something else
-    const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->auto_pipeline && !(p->flags & RR_FLAG_PERSISTENT));
+    const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->auto_pipeline && !(p->flags & (RR_FLAG_PERSISTENT | RR_FLAG_PATHS)));
     const bool paths = !wavefront && !(p->flags & RR_FLAG_PERSISTENT);
     if (wavefront || paths) {
         const uint64_t n_pixels = static_cast<uint64_t>(p->width) * p->height;

@@ -364,8 +364,9 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
         assert one["counters"] == two["counters"]
-        auto = gpu_ctx.render(device.make_params(45, 37, 9, flags=extra, **kw))  # whichever organisation the library picks
-        assert np.array_equal(one["slice_sums"], auto["slice_sums"], equal_nan=True) and one["counters"] == auto["counters"]
+        for flags in (extra, abi.FLAG_PATHS | extra):  # whichever organisation the library picks; the path-granular kernel
+            third = gpu_ctx.render(device.make_params(45, 37, 9, flags=flags, **kw))
+            assert np.array_equal(one["slice_sums"], third["slice_sums"], equal_nan=True) and one["counters"] == third["counters"]
     # a slice range, a sample offset and zero depth go through the same bookkeeping
     for kw2 in (dict(slice_begin=1, slice_end=3), dict(sample_offset=40), dict(max_depth=0), dict(max_depth=1)):
         args = dict(kw)
@@ -387,7 +388,7 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
     kw = dict(n_slices=2, max_depth=40, seed=31)
     one = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_PERSISTENT, **kw))
     monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(80 * 2 * 40 * 32 * 5))  # five samples per slot and batch: 5 batches of 23
-    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, 0):
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_PATHS):
         two = gpu_ctx.render(device.make_params(40, 32, 46, flags=flags, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert one["counters"] == two["counters"]
@@ -426,7 +427,7 @@ def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp
     kw = dict(n_slices=8, max_depth=25, seed=41)
     assert side * side * spp >= 1 << 25
     one = gpu_ctx.render(device.make_params(side, side, spp, flags=abi.FLAG_PERSISTENT, **kw))
-    for flags in (abi.FLAG_WAVEFRONT, 0):
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_PATHS):
         two = gpu_ctx.render(device.make_params(side, side, spp, flags=flags, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
