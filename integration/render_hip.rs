@@ -107,6 +107,27 @@ impl Flattener {
         rr_ref(RR_TAG_LIST, self.lists.len() as u32 - 1)
     }
 
+    /// Same kind, bit-identical fields and the same material: the two clones a span-1 BVH node holds
+    /// (collider.rs:180-182).  Anything that is not a primitive is flattened twice, which renders the same image
+    /// (the second visit repeats the first).
+    fn same_leaf(&mut self, a: &Geometry, b: &Geometry) -> bool {
+        let v = |p: &Vec3| [p.x.to_bits(), p.y.to_bits(), p.z.to_bits()];
+        let f = |x: &[&f32]| x.iter().map(|y| y.to_bits()).collect::<Vec<u32>>();
+        if self.material(&a.material) != self.material(&b.material) { return false; }
+        match (&a.geometry_type, &b.geometry_type) {
+            (GeometryType::Sphere(c0, r0), GeometryType::Sphere(c1, r1)) => v(c0) == v(c1) && r0.to_bits() == r1.to_bits(),
+            (GeometryType::MovingSphere(a0, a1, s0, s1, ra), GeometryType::MovingSphere(b0, b1, t0, t1, rb)) =>
+                v(a0) == v(b0) && v(a1) == v(b1) && f(&[s0, s1, ra]) == f(&[t0, t1, rb]),
+            (GeometryType::Triangle(a0, a1, a2, an), GeometryType::Triangle(b0, b1, b2, bn)) =>
+                v(a0) == v(b0) && v(a1) == v(b1) && v(a2) == v(b2) && v(an) == v(bn),
+            (GeometryType::XYRect(a0, a1, a2, a3, a4), GeometryType::XYRect(b0, b1, b2, b3, b4))
+            | (GeometryType::XZRect(a0, a1, a2, a3, a4), GeometryType::XZRect(b0, b1, b2, b3, b4))
+            | (GeometryType::YZRect(a0, a1, a2, a3, a4), GeometryType::YZRect(b0, b1, b2, b3, b4)) =>
+                f(&[a0, a1, a2, a3, a4]) == f(&[b0, b1, b2, b3, b4]),
+            _ => false,
+        }
+    }
+
     /// One record per node, appended to the array of its kind; returns tag << 28 | index.  The tree is kept
     /// exactly as built: results depend on visit order (collider.rs:555-561, :627).
     fn geometry(&mut self, g: &Geometry) -> u32 {
@@ -122,10 +143,13 @@ impl Flattener {
                 self.moving_spheres.push(rr_moving_sphere { center0: v3(*c0), center1: v3(*c1), time0: *t0, time1: *t1, radius: *r, material, prim_id });
                 rr_ref(RR_TAG_MOVING_SPHERE, self.moving_spheres.len() as u32 - 1)
             }
-            // fields in the enum's order; YZRect's were reordered by its constructor (collider.rs:80-84)
-            GeometryType::XYRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_XY, (*a0, *a1, *b0, *b1, *k), material),
-            GeometryType::XZRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_XZ, (*a0, *a1, *b0, *b1, *k), material),
-            GeometryType::YZRect(a0, a1, b0, b1, k) => self.rect(RR_RECT_YZ, (*a0, *a1, *b0, *b1, *k), material),
+            // rr_rect wants (a0, a1, b0, b1, k) with a = x, b = y for XY; a = x, b = z for XZ; a = y, b = z for YZ
+            // (include/rr_hip.h).  XYRect and XZRect hold their fields in that order (collider.rs:68-79); the yzrect
+            // constructor stores YZRect(z0, z1, y0, y1, k) (collider.rs:80-84, read back in that order at :688), so
+            // its two ranges are swapped back here.
+            GeometryType::XYRect(x0, x1, y0, y1, k) => self.rect(RR_RECT_XY, (*x0, *x1, *y0, *y1, *k), material),
+            GeometryType::XZRect(x0, x1, z0, z1, k) => self.rect(RR_RECT_XZ, (*x0, *x1, *z0, *z1, *k), material),
+            GeometryType::YZRect(z0, z1, y0, y1, k) => self.rect(RR_RECT_YZ, (*y0, *y1, *z0, *z1, *k), material),
             GeometryType::Cuboid(_p0, _p1, sides) => {
                 // the six sides in constructor order (collider.rs:88-95), consecutive in `rects`
                 let first_rect = self.rects.len() as u32;
@@ -152,11 +176,14 @@ impl Flattener {
                 rr_ref(RR_TAG_INSTANCE, self.instances.len() as u32 - 1)
             }
             GeometryType::BVHNode(left, right, aabb, axis) => {
-                // a span-1 node holds two clones of one primitive (collider.rs:180-182): flatten it once.
-                // Box<Geometry> has no identity, so "same primitive" is decided by the builder's span; a
-                // maintainer can carry that as a flag, or compare the two children's fields as done here.
+                // A span-1 node holds two clones of one primitive (collider.rs:180-182); the device wants it
+                // flattened once, the same ref on both sides.  Box<Geometry> has no identity, so the clones are
+                // recognised by value: same kind, bit-identical fields, same material.  Two separately built
+                // siblings that are equal in all of that merge too and share one prim_id; the reference's
+                // HitRecord could not tell them apart either (it carries no primitive identity), and the
+                // image is the same.  A maintainer who wants distinct ids carries the builder's span as a flag.
                 let l = self.geometry(left);
-                let r = if same_leaf(left, right) { l } else { self.geometry(right) };
+                let r = if self.same_leaf(left, right) { l } else { self.geometry(right) };
                 let (bmin, bmax, has_box) = match aabb { Some(b) => (v3(b.minimum), v3(b.maximum), 1), None => ([0.0; 3], [0.0; 3], 0) };
                 self.bvh_nodes.push(rr_bvh_node { bmin, bmax, left: l, right: r, axis: *axis as u32, has_box });
                 rr_ref(RR_TAG_BVH, self.bvh_nodes.len() as u32 - 1)
@@ -171,17 +198,6 @@ impl Flattener {
                 rr_ref(RR_TAG_TRIANGLE, self.triangles.len() as u32 - 1)
             }
         }
-    }
-}
-
-/// Two leaves with bit-identical fields: the two clones a span-1 BVH node holds (collider.rs:180-182).
-fn same_leaf(a: &Geometry, b: &Geometry) -> bool {
-    let bits = |v: &Vec3| [v.x.to_bits(), v.y.to_bits(), v.z.to_bits()];
-    match (&a.geometry_type, &b.geometry_type) {
-        (GeometryType::Sphere(c0, r0), GeometryType::Sphere(c1, r1)) => bits(c0) == bits(c1) && r0.to_bits() == r1.to_bits(),
-        (GeometryType::Triangle(a0, a1, a2, _), GeometryType::Triangle(b0, b1, b2, _)) => bits(a0) == bits(b0) && bits(a1) == bits(b1) && bits(a2) == bits(b2),
-        (GeometryType::MovingSphere(a0, a1, ..), GeometryType::MovingSphere(b0, b1, ..)) => bits(a0) == bits(b0) && bits(a1) == bits(b1),
-        _ => false, // other kinds under a span-1 node: flattened twice, which renders the same image (the second visit repeats the first)
     }
 }
 
