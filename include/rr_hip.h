@@ -222,6 +222,13 @@ typedef struct rr_render_params {
     uint32_t sample_offset;     /* added to the per-pixel sample number in the RNG key:
                                    gives each GPU of a weak-scaling job its own samples   */
     uint32_t flags;             /* RR_FLAG_* */
+    uint32_t row_begin, row_end; /* image rows [row_begin,row_end) this call renders, row 0 = top; row_end = 0
+                                    stands for `height` (a zeroed pair is the whole image).  A band of rows is
+                                    how several GPUs share the PIXELS of one image (slices share its SAMPLES,
+                                    render.rs:130-140); every random stream is keyed by the pixel's position in
+                                    the whole image, so the bands of an image are bit for bit the rows of the
+                                    whole render.  Every output of the call has the band's shape,
+                                    (row_end-row_begin) x width x 3, and bands are contiguous in the image.   */
 } rr_render_params;
 
 #define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests; this build of the kernels makes
@@ -301,7 +308,8 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
 /* Render slices [slice_begin, slice_end) of the image; replaces the parallel
  * loop of render_multi (render.rs:135-151) and render_worker (render.rs:89-124).
  * All output pointers are DEVICE pointers owned by the caller, any of the
- * optional ones may be NULL:
+ * optional ones may be NULL; H below is the number of rows the call renders
+ * (row_end-row_begin, the image height unless a band of rows is asked for):
  *   d_slice_sums : (slice_end-slice_begin) × H × W × 3 f32, the per-slice pixel sums
  *                  (pixel_color of render.rs:93-100, NaN kept), row 0 = top.  Required.
  *   d_resolved   : H × W × 3 f32, Σ over the rendered slices of the per-slice
@@ -311,7 +319,13 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
  *                  pixel sums (linear radiance × samples).          Optional.
  *   d_counters   : one rr_counters, ADDED to (caller zeroes it).   Optional.
  * Work is enqueued on hip_stream (a hipStream_t, NULL = default stream) and the
- * call returns without synchronising.  Part of the wavefront pipeline's work runs
+ * call returns without synchronising, with one exception: the first call, and any call that
+ * needs a larger workspace than every call before it, (re)allocates the context's grow-only
+ * workspace, which waits for the device (hipDeviceSynchronize + hipFree + hipMalloc).
+ * ONE render per context may be in flight at a time: the workspace, the work counters, the
+ * library's second stream and the timing events belong to the context, so a second
+ * rr_render_device on another stream must be ordered after the first (same stream, or an
+ * event); independent concurrent renders take one context each.  Part of the wavefront pipeline's work runs
  * on a stream of the library's own, ordered against hip_stream by events, so
  * whatever the caller enqueues on hip_stream afterwards sees the result.        */
 int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,

@@ -256,7 +256,7 @@ pub fn render_hip(scene: SceneColliders, lights: Geometry, cam: Camera, backgrou
     check(unsafe { rr_scene_upload(ctx, &flat) });
     let k = num_cpus::get() as u32; // render.rs:129: the 8-bit image depends on the slice count (render.rs:102-119)
     let p = rr_render_params { width: img_width, height: img_height, samples_per_pixel: samples_per_pixel as u32, n_slices: k, slice_begin: 0,
-                               slice_end: k, max_depth: max_depth as u32, seed: rand::random(), sample_offset: 0, flags: 0 };
+                               slice_end: k, max_depth: max_depth as u32, seed: rand::random(), sample_offset: 0, flags: 0, row_begin: 0, row_end: 0 };
     let mut rgb = vec![0u8; (img_width * img_height * 3) as usize];
     check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
     unsafe { rr_context_destroy(ctx) };

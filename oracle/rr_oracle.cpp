@@ -780,22 +780,27 @@ int rro_render(const rr_flat_scene* s, const rr_render_params* p, float* slice_s
     if (p->n_slices == 0 || p->slice_begin > p->slice_end || p->slice_end > p->n_slices || p->width == 0 || p->height == 0)
         return RR_E_INVALID;
     const uint32_t W = p->width, H = p->height;
+    // the band of image rows [row_begin, row_end) (row_end = 0: the image height); outputs have the band's shape
+    const uint32_t row_end = p->row_end == 0 ? H : p->row_end;
+    if (p->row_begin > row_end || row_end > H) return RR_E_INVALID;
+    const uint32_t R0 = p->row_begin, R = row_end - p->row_begin;
     const uint32_t spt = p->samples_per_pixel / p->n_slices;  // render.rs:130
     const uint32_t n_sl = p->slice_end - p->slice_begin;
-    const size_t npix = static_cast<size_t>(W) * H;
+    const size_t npix = static_cast<size_t>(W) * R;
     if (n_threads < 1) n_threads = 1;
     std::atomic<uint64_t> next{0};
-    const uint64_t n_tasks = static_cast<uint64_t>(n_sl) * H;
+    const uint64_t n_tasks = static_cast<uint64_t>(n_sl) * R;
     std::vector<rr_counters> tc(static_cast<size_t>(n_threads));
     auto worker = [&](int tid) {
         rr_counters* cnt = counters ? &tc[tid] : nullptr;
         for (;;) {
             uint64_t task = next.fetch_add(1);
             if (task >= n_tasks) break;
-            const uint32_t sl = static_cast<uint32_t>(task / H);
-            const uint32_t j = H - 1 - static_cast<uint32_t>(task % H);  // rows top to bottom, as render.rs:91
+            const uint32_t sl = static_cast<uint32_t>(task / R);
+            const uint32_t row = R0 + static_cast<uint32_t>(task % R);  // rows top to bottom, as render.rs:91
+            const uint32_t j = H - 1 - row;
             const uint32_t k = p->slice_begin + sl;
-            float* dst = slice_sums + (static_cast<size_t>(sl) * npix + static_cast<size_t>(H - 1 - j) * W) * 3;
+            float* dst = slice_sums + (static_cast<size_t>(sl) * npix + static_cast<size_t>(row - R0) * W) * 3;
             for (uint32_t i = 0; i < W; ++i) {
                 V3 pixel = mk(0, 0, 0);
                 for (uint32_t q = 0; q < spt; ++q) {

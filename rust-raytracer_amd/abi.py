@@ -122,7 +122,13 @@ class FlatScene(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("samples_per_pixel", u32), ("n_slices", u32), ("slice_begin", u32),
-                ("slice_end", u32), ("max_depth", u32), ("seed", u64), ("sample_offset", u32), ("flags", u32)]
+                ("slice_end", u32), ("max_depth", u32), ("seed", u64), ("sample_offset", u32), ("flags", u32),
+                ("row_begin", u32), ("row_end", u32)]
+
+    @property
+    def rows(self):
+        """Number of image rows the call renders (row_end = 0 stands for the image height)."""
+        return (self.row_end or self.height) - self.row_begin
 
 
 class Counters(C.Structure):

@@ -25,7 +25,8 @@ using namespace rrdev;
 #define RR_RENDER_WAVES_PER_SIMD 4
 #endif
 struct RenderArgs {
-    uint32_t width, height;
+    uint32_t width, height; // of the whole image
+    uint32_t row0, rows;    // the band of image rows [row0, row0 + rows) this launch renders
     uint32_t spt;           // samples per slice and pixel (render.rs:130)
     uint32_t tiles_x;       // 8x8 pixel tiles per row
     uint32_t padded_pixels; // tiles * 64
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
     for (;;) {
         // ---- lanes whose path ended: pixel_color of render.rs:93-100 is complete for this slice once the item's samples are through
         auto finish_item = [&]() {
-            float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.height + py) * a.width + px) * 3u;
+            float* dst = slice_sums + ((static_cast<uint64_t>(a.slice_out + sl) * a.rows + py) * a.width + px) * 3u;
             dst[0] = acc.x;
             dst[1] = acc.y;
             dst[2] = acc.z;
@@ -120,11 +121,11 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
                 const uint32_t tile = r >> 6, within = r & 63u;
                 px = (tile % a.tiles_x) * 8u + (within & 7u);
                 py = (tile / a.tiles_x) * 8u + (within >> 3);
-                if (px < a.width && py < a.height) {  // (items of the padding around the image are dropped)
+                if (px < a.width && py < a.rows) {  // (items of the padding around the band are dropped)
                     have_item = true;
                     s = 0;
                     acc = mk3(0.f, 0.f, 0.f);
-                    pixel_key = py * a.width + px;
+                    pixel_key = (a.row0 + py) * a.width + px;
                     if (a.spt == 0) finish_item();
                 }
             }
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
             sample = a.sample_offset + (a.slice_first + sl) * a.spt + s;
             Rng g;
             g.start(a.seed, pixel_key, sample, CAMERA_BOUNCE);
-            camera_ray(sc, a.width, a.height, px, a.height - 1u - py, g, ro, rd, time);
+            camera_ray(sc, a.width, a.height, px, a.height - 1u - (a.row0 + py), g, ro, rd, time);
             thr = mk3(1.f, 1.f, 1.f);
             depth_left = a.max_depth;
             bounce = 0;
@@ -695,11 +696,20 @@ int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid
     return RR_OK;
 }
 
-int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t n_sl, uint32_t spt, void* d_slice_sums, void* d_resolved,
+// The band of image rows a call renders: [row_begin, row_end), row_end = 0 standing for the image height.
+bool band_of(const rr_render_params* p, uint32_t* row0, uint32_t* rows) {
+    const uint32_t end = p->row_end == 0 ? p->height : p->row_end;
+    if (p->row_begin > end || end > p->height) return false;
+    *row0 = p->row_begin;
+    *rows = end - p->row_begin;
+    return true;
+}
+
+int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t rows, uint32_t n_sl, uint32_t spt, void* d_slice_sums, void* d_resolved,
                    void* d_linear, hipStream_t stream) {
     (void)ctx;
-    if (d_resolved || d_linear) {
-        const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
+    if ((d_resolved || d_linear) && rows != 0) {
+        const uint64_t n_elems = static_cast<uint64_t>(p->width) * rows * 3u;
         const uint32_t g = static_cast<uint32_t>((n_elems + 255u) / 256u);
         hipLaunchKernelGGL(k_resolve, dim3(g), dim3(256), 0, stream, static_cast<const float*>(d_slice_sums), n_sl, n_elems,
                            1.0f / static_cast<float>(spt), static_cast<float>(p->n_slices), static_cast<float*>(d_resolved),
@@ -1316,6 +1326,8 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     if (p->width == 0 || p->height == 0 || p->n_slices == 0 || p->slice_begin > p->slice_end || p->slice_end > p->n_slices)
         return fail(RR_E_INVALID, "rr_render_device: bad image size or slice range");
     if (static_cast<uint64_t>(p->width) * p->height > 0xFFFFFFFFull) return fail(RR_E_LIMIT, "rr_render_device: more than 2^32 pixels");
+    uint32_t row0 = 0, rows = 0;
+    if (!band_of(p, &row0, &rows)) return fail(RR_E_INVALID, "rr_render_device: bad row range");
     if (int rc = set_device(ctx)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const uint32_t n_sl = p->slice_end - p->slice_begin;
@@ -1326,13 +1338,20 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     // the persistent kernel at path granularity (k_wf_paths) unless the scene is one for the pipeline or a flag asks for something else
     const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->auto_pipeline && !(p->flags & (RR_FLAG_PERSISTENT | RR_FLAG_PATHS)));
     const bool paths = !wavefront && !(p->flags & RR_FLAG_PERSISTENT);
+    if (rows == 0) {  // an empty band: nothing to render, nothing to write
+        HIP_TRY(hipEventRecord(ctx->ev0, stream));
+        HIP_TRY(hipEventRecord(ctx->ev1, stream));
+        ctx->timed = true;
+        return RR_OK;
+    }
     if (wavefront || paths) {
-        const uint64_t n_pixels = static_cast<uint64_t>(p->width) * p->height;
+        const uint64_t n_pixels = static_cast<uint64_t>(p->width) * rows;
         if (n_pixels > (1ull << 30)) return fail(RR_E_LIMIT, "rr_render_device: more than 2^30 pixels in one wavefront pass");
         WfArgs w{};
         w.width = p->width;
         w.height = p->height;
         w.n_pixels = static_cast<uint32_t>(n_pixels);
+        w.pixel0 = row0 * p->width;
         w.spt = spt;
         w.max_depth = p->max_depth;
         w.sample_offset = p->sample_offset;
@@ -1351,7 +1370,7 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
         }
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         ctx->timed = true;
-        return resolve_slices(ctx, p, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
+        return resolve_slices(ctx, p, rows, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
     }
     using RenderKernel = void (*)(DevScene, RenderArgs, float*, unsigned long long*);
     const RenderKernel render_kernel = ctx->prog_vector_ops ? (count ? k_render<true, true> : k_render<false, true>)
@@ -1364,14 +1383,16 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     RenderArgs a{};
     a.width = p->width;
     a.height = p->height;
+    a.row0 = row0;
+    a.rows = rows;
     a.spt = spt;
     a.tiles_x = (p->width + 7u) / 8u;
-    a.padded_pixels = a.tiles_x * ((p->height + 7u) / 8u) * 64u;
+    a.padded_pixels = a.tiles_x * ((rows + 7u) / 8u) * 64u;
     a.max_depth = p->max_depth;
     a.sample_offset = p->sample_offset;
     a.seed = p->seed;
     // Slices are rendered in groups so that one launch stays within about 2^31 samples.
-    const uint64_t samples_per_slice = static_cast<uint64_t>(p->width) * p->height * std::max(spt, 1u);
+    const uint64_t samples_per_slice = static_cast<uint64_t>(p->width) * rows * std::max(spt, 1u);
     uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (1ull << 31) / samples_per_slice));
     if (!ctx->next_item) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->next_item), sizeof(unsigned long long)));
     a.next_item = ctx->next_item;
@@ -1390,7 +1411,7 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     }
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
-    return resolve_slices(ctx, p, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
+    return resolve_slices(ctx, p, rows, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
 }
 
 int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uint64_t n, void* hip_stream) {
@@ -1419,8 +1440,11 @@ int rr_render(rr_context* ctx, const rr_render_params* p, uint8_t* out_rgb8, flo
     if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_render: no scene uploaded");
     if (p->slice_begin > p->slice_end || p->slice_end > p->n_slices || p->n_slices == 0 || p->width == 0 || p->height == 0)
         return fail(RR_E_INVALID, "rr_render: bad image size or slice range");
+    uint32_t row0 = 0, rows = 0;
+    if (!band_of(p, &row0, &rows)) return fail(RR_E_INVALID, "rr_render: bad row range");
     if (int rc = set_device(ctx)) return rc;
-    const uint64_t n_elems = static_cast<uint64_t>(p->width) * p->height * 3u;
+    const uint64_t n_out = static_cast<uint64_t>(p->width) * rows * 3u;  // elements of one output image (a band of rows)
+    const uint64_t n_elems = std::max<uint64_t>(1, n_out);                // (an empty band still gets buffers)
     const uint32_t n_sl = p->slice_end - p->slice_begin;
     float *d_sums = nullptr, *d_res = nullptr, *d_lin = nullptr;
     uint8_t* d_u8 = nullptr;
@@ -1444,16 +1468,16 @@ int rr_render(rr_context* ctx, const rr_render_params* p, uint8_t* out_rgb8, flo
     if ((e = hipMalloc(&d_cnt, sizeof(rr_counters))) != hipSuccess) return hip_fail(e);
     if ((e = hipMemset(d_cnt, 0, sizeof(rr_counters))) != hipSuccess) return hip_fail(e);
     int rc = rr_render_device(ctx, p, d_sums, d_res, d_lin, d_cnt, nullptr);
-    if (rc == RR_OK) rc = rr_cast_u8_device(ctx, d_res, d_u8, n_elems, nullptr);
+    if (rc == RR_OK) rc = rr_cast_u8_device(ctx, d_res, d_u8, n_out, nullptr);
     if (rc != RR_OK) {
         cleanup();
         return rc;
     }
     if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e);
-    if (out_rgb8 && (e = hipMemcpy(out_rgb8, d_u8, n_elems, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
-    if (out_resolved && (e = hipMemcpy(out_resolved, d_res, n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
-    if (out_linear && (e = hipMemcpy(out_linear, d_lin, n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
-    if (out_slice_sums && n_sl && (e = hipMemcpy(out_slice_sums, d_sums, static_cast<uint64_t>(n_sl) * n_elems * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+    if (out_rgb8 && n_out && (e = hipMemcpy(out_rgb8, d_u8, n_out, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_resolved && n_out && (e = hipMemcpy(out_resolved, d_res, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_linear && n_out && (e = hipMemcpy(out_linear, d_lin, n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
+    if (out_slice_sums && n_sl && n_out && (e = hipMemcpy(out_slice_sums, d_sums, static_cast<uint64_t>(n_sl) * n_out * 4, hipMemcpyDeviceToHost)) != hipSuccess)
         return hip_fail(e);
     if (out_counters && (e = hipMemcpy(out_counters, d_cnt, sizeof(rr_counters), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
     cleanup();

@@ -54,7 +54,9 @@ struct WfCtl {
     uint32_t cursor;  // next entry no traversal wave has claimed yet
 };
 struct WfArgs {
-    uint32_t width, height, n_pixels;
+    uint32_t width, height;  // of the whole image
+    uint32_t n_pixels;       // pixels of the band of rows this call renders (the whole image unless rr_render_params asks for a band)
+    uint32_t pixel0;         // position of the band's first pixel in the whole image (row_begin * width)
     uint32_t n_slots;      // slices in this pass * n_pixels
     uint32_t n_paths;      // n_slots * samples in this batch; path p is sample s0 + p / n_slots of slot p % n_slots
     uint32_t s0;           // first sample of the batch within its slice
@@ -66,10 +68,11 @@ struct WfArgs {
     uint64_t seed;
 };
 
-// (pixel, per-pixel sample number) of a path: the key of its random streams.
+// (pixel, per-pixel sample number) of a path: the key of its random streams.  The pixel is its position in the whole
+// image (row * width + column), whichever band of rows is being rendered.
 __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_t& pixel, uint32_t& sample) {
     const uint32_t slot = p % a.n_slots, s = a.s0 + p / a.n_slots;
-    pixel = slot % a.n_pixels;
+    pixel = a.pixel0 + slot % a.n_pixels;
     sample = a.sample_offset + (a.slice_first + slot / a.n_pixels) * a.spt + s;
 }
 

@@ -43,9 +43,9 @@ HIT_DTYPE = np.dtype([("prim_id", "<i4"), ("material", "<u4"), ("t", "<f4"), ("p
 
 
 def make_params(width, height, spp, n_slices=1, max_depth=50, seed=1, slice_begin=0, slice_end=None, sample_offset=0,
-                flags=0):
+                flags=0, row_begin=0, row_end=0):
     return abi.RenderParams(width, height, spp, n_slices, slice_begin, n_slices if slice_end is None else slice_end,
-                            max_depth, seed, sample_offset, flags)
+                            max_depth, seed, sample_offset, flags, row_begin, row_end)
 
 
 class Context:
@@ -88,8 +88,8 @@ class Context:
 
     def render(self, params, slice_sums=True):
         """Synchronous render into host arrays → dict(rgb8, resolved, linear, slice_sums, counters)."""
-        h, w = params.height, params.width
-        k = params.slice_end - params.slice_begin
+        h, w = max(0, params.rows), params.width  # (a reversed row range is the library's to report)
+        k = max(0, params.slice_end - params.slice_begin)
         rgb = np.zeros((h, w, 3), dtype=np.uint8)
         res = np.zeros((h, w, 3), dtype=np.float32)
         lin = np.zeros((h, w, 3), dtype=np.float32)

@@ -57,15 +57,15 @@ def primary_hits(flat, rays, t_min=0.001, t_max=3.40282347e38, seed=0, counters=
 
 
 def make_params(width, height, spp, n_slices=1, max_depth=50, seed=1, slice_begin=0, slice_end=None, sample_offset=0,
-                flags=0):
+                flags=0, row_begin=0, row_end=0):
     return abi.RenderParams(width, height, spp, n_slices, slice_begin, n_slices if slice_end is None else slice_end,
-                            max_depth, seed, sample_offset, flags)
+                            max_depth, seed, sample_offset, flags, row_begin, row_end)
 
 
 def render(flat, params, n_threads=8, counters=False):
     """→ dict(slice_sums[K',H,W,3], resolved[H,W,3], linear[H,W,3], rgb8[H,W,3], counters)"""
     k = params.slice_end - params.slice_begin
-    h, w = params.height, params.width
+    h, w = params.rows, params.width
     ss = np.zeros((k, h, w, 3), dtype=np.float32)
     res = np.zeros((h, w, 3), dtype=np.float32)
     lin = np.zeros((h, w, 3), dtype=np.float32)

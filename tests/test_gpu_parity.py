@@ -456,6 +456,44 @@ def test_render_is_deterministic_and_slices_compose(gpu_ctx):
     assert not np.array_equal(other_seed["slice_sums"], full["slice_sums"])
 
 
+@pytest.mark.parametrize("name", ["cornell", "suzanne", "spheres"])
+def test_bands_of_rows_and_slice_halves_recompose_the_image(gpu_ctx, name):
+    """How several GPUs share one image (rust_raytracer_amd.multi), on one GPU: bands of rows rendered on their own are
+    bit for bit the rows of the whole render in every kernel organisation (random streams are keyed by the pixel's
+    place in the whole image), and so are slice ranges; bands x slice halves together give back the 8-bit image."""
+    from rust_raytracer_amd import multi
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    W, H, K, spp = 70, 45, 4, 12
+    job = multi.job_params(W, H, spp, K, 25, 9)
+    whole = gpu_ctx.render(job)
+    for flags in (0, abi.FLAG_PERSISTENT, abi.FLAG_WAVEFRONT, abi.FLAG_PATHS, abi.FLAG_COUNTERS):
+        for r0, r1 in ((0, 17), (17, 45), (44, 45), (5, 5)):
+            band = gpu_ctx.render(device.make_params(W, H, spp, n_slices=K, max_depth=25, seed=9, flags=flags, row_begin=r0, row_end=r1))
+            assert band["slice_sums"].shape == (K, r1 - r0, W, 3)
+            assert np.array_equal(band["slice_sums"], whole["slice_sums"][:, r0:r1], equal_nan=True), (flags, r0, r1)
+            assert np.array_equal(band["rgb8"], whole["rgb8"][r0:r1]) and np.array_equal(band["resolved"], whole["resolved"][r0:r1], equal_nan=True)
+            assert band["counters"]["samples"] == (r1 - r0) * W * spp
+    for world, partition in ((4, "both"), (3, "rows"), (2, "slices")):
+        bands, groups = multi.grid(world, partition)
+        resolved = np.zeros((H, W, 3), dtype=np.float32)
+        rays = 0
+        for rank in range(world):
+            p = multi.rank_share(job, rank, world, partition)
+            r = gpu_ctx.render(p)
+            assert np.array_equal(r["slice_sums"], whole["slice_sums"][p.slice_begin:p.slice_end, p.row_begin:p.row_end], equal_nan=True)
+            resolved[p.row_begin:p.row_end] += r["resolved"]  # the reduce over slice groups; bands are disjoint
+            rays += r["counters"]["rays"]
+        assert rays == whole["counters"]["rays"]
+        if groups == 1:
+            assert np.array_equal(resolved, whole["resolved"])
+        assert np.abs(O.cast_u8(resolved).astype(int) - whole["rgb8"].astype(int)).max() <= 1
+    with pytest.raises(device.DeviceError, match="row"):
+        gpu_ctx.render(device.make_params(W, H, spp, n_slices=K, row_begin=10, row_end=H + 1))
+    with pytest.raises(device.DeviceError, match="row"):
+        gpu_ctx.render(device.make_params(W, H, spp, n_slices=K, row_begin=10, row_end=9))
+
+
 def test_full_size_cornell_configuration(gpu_ctx):
     """The headline benchmark configuration at full size (Cornell box, 600x600, 1000 spp, depth 200): every sample is traced,
     nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""
