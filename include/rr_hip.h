@@ -331,6 +331,25 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
 int rr_render_device(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
                      void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
 
+/* rr_render_device for callers that cannot allocate device memory.  It has no counterpart in the
+ * reference: it is for hosts that call from inside a HIP graph capture, from a tight serving loop or
+ * under a harness that forbids hipMalloc.  Same arguments, same outputs and the same bits as
+ * rr_render_device, with two differences:
+ *   - it calls no hipMalloc, hipFree or other allocating routine: the kernels' workspace (the counter
+ *     the waves claim paths from, and 16 bytes of sample value per path in flight) is a static device
+ *     array of 64 MiB + 256 bytes inside the library, which every GPU the library runs on holds
+ *     until the process ends;
+ *   - it always renders with the path-granular persistent kernel (RR_FLAG_PERSISTENT, RR_FLAG_WAVEFRONT and
+ *     RR_FLAG_NO_FINISH_KERNEL are rejected with RR_E_INVALID), a group of slices and a batch of samples at a
+ *     time, at most RR_NOALLOC_MAX_PATHS paths in flight.
+ * Limit: width x (rows of the call) <= RR_NOALLOC_MAX_PATHS, else RR_E_LIMIT (render the image in bands
+ * of rows, row_begin/row_end).  All calls on one GPU share that GPU's array: two calls that overlap in
+ * time on one GPU (different streams, different contexts, different threads) race and corrupt each
+ * other's images; calls on one stream, or ordered by events, are fine.                              */
+#define RR_NOALLOC_MAX_PATHS 4194304u
+int rr_render_device_noalloc(rr_context* ctx, const rr_render_params* params, void* d_slice_sums,
+                             void* d_resolved, void* d_linear, void* d_counters, void* hip_stream);
+
 /* Convenience wrapper for hosts without their own device buffers: allocates,
  * renders all of [slice_begin,slice_end), synchronises and copies to HOST
  * buffers.  out_rgb8 (H×W×3 u8) is the saturating `as u8` cast of render.rs:156-159

@@ -24,6 +24,7 @@ FLAG_WAVEFRONT = 4
 FLAG_NO_FINISH_KERNEL = 8
 FLAG_PATHS = 16
 PERLIN_POINTS = 256
+NOALLOC_MAX_PATHS = 4194304
 
 
 def ref(tag, index):
@@ -172,6 +173,7 @@ HIP_PROTOTYPES = {
     "rr_scene_info_get": (C.c_int, [vp, P(SceneInfo)]),
     "rr_primary_hits": (C.c_int, [vp, u32, f3, f32, f32, u64, P(Hit)]),
     "rr_render_device": (C.c_int, [vp, P(RenderParams), vp, vp, vp, vp, vp]),
+    "rr_render_device_noalloc": (C.c_int, [vp, P(RenderParams), vp, vp, vp, vp, vp]),
     "rr_render": (C.c_int, [vp, P(RenderParams), P(u8), f3, f3, f3, P(Counters)]),
     "rr_cast_u8_device": (C.c_int, [vp, vp, vp, u64, vp]),
     "rr_last_kernel_ms": (C.c_int, [vp, f3]),

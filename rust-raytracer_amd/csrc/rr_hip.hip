@@ -248,6 +248,15 @@ __global__ void __launch_bounds__(256) k_cast_u8(const float* __restrict__ src, 
 
 #include "rr_wavefront.h"
 
+// Device memory of rr_render_device_noalloc, the entry point that allocates nothing: the counter its waves claim paths
+// from (first 256 bytes) and the sample values of the paths in flight (16 bytes each).  One copy per GPU, held until
+// the process ends.  Host code reaches it only through the address hipGetSymbolAddress returns for the current device
+// (rr_context::scratch); the array's name is not a device address on the host.
+constexpr size_t RR_SCRATCH_HEADER = 256;
+constexpr size_t RR_SCRATCH_PATHS = static_cast<size_t>(RR_NOALLOC_MAX_PATHS);
+constexpr size_t RR_SCRATCH_BYTES = RR_SCRATCH_HEADER + RR_SCRATCH_PATHS * 16u;
+static __device__ __align__(256) unsigned char scratch[RR_SCRATCH_BYTES];
+
 // ============================================================ host side
 namespace {
 
@@ -298,6 +307,7 @@ struct rr_context {
     size_t wf_bytes = 0;
     uint32_t* wf_host_count = nullptr;
     unsigned long long* next_item = nullptr;  // k_render's work-item counter (device memory)
+    unsigned char* scratch = nullptr;             // this device's copy of the file-scope array `scratch` (rr_render_device_noalloc)
     hipStream_t wf_aux = nullptr;                 // k_wf_finish and the accumulation of a batch run here, beside the next batch
     hipEvent_t wf_ev_main[2] = {nullptr, nullptr};  // per workspace: the batch's bounce loop is enqueued
     hipEvent_t wf_ev_aux[2] = {nullptr, nullptr};   // per workspace: the batch is accumulated, the workspace is free
@@ -874,8 +884,42 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     return RR_OK;
 }
 
-// The persistent renderer at path granularity (scenes without BVH subtrees): batches of samples of every slot, each one
-// launch of k_wf_paths that leaves every sample's value in the workspace, and the in-order accumulation of the batch.
+// The persistent renderer at path granularity: batches of samples of every slot, each one launch of k_wf_paths that
+// leaves every sample's value in `values` (room for `capacity` paths), and the in-order accumulation of the batch.
+// Allocates nothing: the caller brings the values' memory and the device word the waves claim their paths from.
+int render_paths_in(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream, float4* values,
+                    uint64_t capacity, unsigned int* next_path) {
+    const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, capacity / a.n_slots);
+    if (most == 0) return fail(RR_E_LIMIT, "render_paths: the sample values of one sample per (slice, pixel) do not fit the workspace");
+    const uint64_t batch = std::min<uint64_t>(most, std::max(a.spt, 1u));
+    WfState st{};
+    st.thr = values;
+    using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
+    const PathsKernel kernel = ctx->has_subtrees ? (count ? k_wf_paths<true, true, true> : k_wf_paths<false, true, true>)
+                               : ctx->prog_vector_ops ? (count ? k_wf_paths<true, true> : k_wf_paths<false, true>)
+                                                      : (count ? k_wf_paths<true, false> : k_wf_paths<false, false>);
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    int grid = 0;
+    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
+    const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
+    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
+        a.s0 = s0;
+        a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        if (a.n_paths != 0) {
+            HIP_TRY(hipMemsetAsync(next_path, 0, sizeof(unsigned long long), stream));
+            const uint32_t g = std::min<uint32_t>(static_cast<uint32_t>(grid), (a.n_paths + 255u) / 256u);
+            hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, next_path, counters);
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
+        HIP_TRY(hipGetLastError());
+        if (a.spt == 0) break;
+    }
+    return RR_OK;
+}
+
+// render_paths_in with the context's grow-only workspace: as many samples per slot in flight as min(16 GiB, a quarter of
+// free HBM) holds.
 int render_paths(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -896,30 +940,8 @@ int render_paths(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned lo
         ctx->wf_bytes = need;
     }
     if (!ctx->next_item) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->next_item), sizeof(unsigned long long)));
-    WfState st{};
-    st.thr = static_cast<float4*>(ctx->wf_mem);
-    using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
-    const PathsKernel kernel = ctx->has_subtrees ? (count ? k_wf_paths<true, true, true> : k_wf_paths<false, true, true>)
-                               : ctx->prog_vector_ops ? (count ? k_wf_paths<true, true> : k_wf_paths<false, true>)
-                                                      : (count ? k_wf_paths<true, false> : k_wf_paths<false, false>);
-    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
-    int grid = 0;
-    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
-    const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
-    for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
-        a.s0 = s0;
-        a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
-        if (a.n_paths != 0) {
-            HIP_TRY(hipMemsetAsync(ctx->next_item, 0, sizeof(unsigned long long), stream));
-            const uint32_t g = std::min<uint32_t>(static_cast<uint32_t>(grid), (a.n_paths + 255u) / 256u);
-            hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, reinterpret_cast<unsigned int*>(ctx->next_item), counters);
-            HIP_TRY(hipGetLastError());
-        }
-        hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
-        HIP_TRY(hipGetLastError());
-        if (a.spt == 0) break;
-    }
-    return RR_OK;
+    return render_paths_in(ctx, a, count, sums, counters, stream, static_cast<float4*>(ctx->wf_mem), static_cast<uint64_t>(a.n_slots) * batch,
+                           reinterpret_cast<unsigned int*>(ctx->next_item));
 }
 
 }  // namespace
@@ -957,6 +979,16 @@ int rr_context_create(int device, rr_context** out) {
         delete ctx;
         return fail(RR_E_HIP, "hipEventCreate failed");
     }
+    // this device's copy of the static array behind rr_render_device_noalloc (every GPU has its own, at its own address)
+    void* scratch_ptr = nullptr;
+    const hipError_t se = hipGetSymbolAddress(&scratch_ptr, HIP_SYMBOL(scratch));
+    if (se != hipSuccess || !scratch_ptr) {
+        (void)hipEventDestroy(ctx->ev0);
+        (void)hipEventDestroy(ctx->ev1);
+        delete ctx;
+        return fail(RR_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(se));
+    }
+    ctx->scratch = static_cast<unsigned char*>(scratch_ptr);
     *out = ctx;
     return RR_OK;
 }
@@ -1319,8 +1351,11 @@ int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min,
     return RR_OK;
 }
 
-int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear,
-                     void* d_counters, void* hip_stream) {
+}  // extern "C"
+
+namespace {
+int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear, void* d_counters,
+                  void* hip_stream, bool noalloc) {
     if (!ctx || !p || !d_slice_sums) return fail(RR_E_INVALID, "rr_render_device: NULL argument");
     if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_render_device: no scene uploaded");
     if (p->width == 0 || p->height == 0 || p->n_slices == 0 || p->slice_begin > p->slice_end || p->slice_end > p->n_slices)
@@ -1336,8 +1371,11 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     if (((p->flags & RR_FLAG_PERSISTENT) != 0) + ((p->flags & RR_FLAG_WAVEFRONT) != 0) + ((p->flags & RR_FLAG_PATHS) != 0) > 1)
         return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT, RR_FLAG_WAVEFRONT and RR_FLAG_PATHS exclude each other");
     // the persistent kernel at path granularity (k_wf_paths) unless the scene is one for the pipeline or a flag asks for something else
-    const bool wavefront = (p->flags & RR_FLAG_WAVEFRONT) || (ctx->auto_pipeline && !(p->flags & (RR_FLAG_PERSISTENT | RR_FLAG_PATHS)));
-    const bool paths = !wavefront && !(p->flags & RR_FLAG_PERSISTENT);
+    if (noalloc && (p->flags & (RR_FLAG_PERSISTENT | RR_FLAG_WAVEFRONT | RR_FLAG_NO_FINISH_KERNEL)))
+        return fail(RR_E_INVALID, "rr_render_device_noalloc renders with the path-granular kernel only: RR_FLAG_PERSISTENT, RR_FLAG_WAVEFRONT and "
+                                  "RR_FLAG_NO_FINISH_KERNEL do not apply");
+    const bool wavefront = !noalloc && ((p->flags & RR_FLAG_WAVEFRONT) || (ctx->auto_pipeline && !(p->flags & (RR_FLAG_PERSISTENT | RR_FLAG_PATHS))));
+    const bool paths = noalloc || (!wavefront && !(p->flags & RR_FLAG_PERSISTENT));
     if (rows == 0) {  // an empty band: nothing to render, nothing to write
         HIP_TRY(hipEventRecord(ctx->ev0, stream));
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
@@ -1356,17 +1394,28 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
         w.max_depth = p->max_depth;
         w.sample_offset = p->sample_offset;
         w.seed = p->seed;
-        // slices go through in groups of at most 2^27 slots (72 bytes of path state and queues each)
-        const uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (1ull << 27) / n_pixels));
+        // slices go through in groups of at most 2^27 slots (72 bytes of path state and queues each); without allocations, of
+        // as many slots as the static scratch holds sample values for
+        if (noalloc && n_pixels > RR_SCRATCH_PATHS)
+            return fail(RR_E_LIMIT, "rr_render_device_noalloc: " + std::to_string(n_pixels) + " pixels in one call, the static workspace holds " +
+                                        std::to_string(RR_SCRATCH_PATHS) + " (render the image in bands of rows)");
+        const uint32_t group = static_cast<uint32_t>(std::max<uint64_t>(1, (noalloc ? RR_SCRATCH_PATHS : (1ull << 27)) / n_pixels));
         HIP_TRY(hipEventRecord(ctx->ev0, stream));
         for (uint32_t s0 = 0; s0 < n_sl; s0 += group) {
             const uint32_t here = std::min(group, n_sl - s0);
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.slice_first = p->slice_begin + s0;
             w.slice_out = s0;
-            if (int rc = paths ? render_paths(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream)
-                               : render_wavefront(ctx, w, count, p->flags, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream))
-                return rc;
+            int rc;
+            if (noalloc)
+                rc = render_paths_in(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream,
+                                     reinterpret_cast<float4*>(ctx->scratch + RR_SCRATCH_HEADER), RR_SCRATCH_PATHS,
+                                     reinterpret_cast<unsigned int*>(ctx->scratch));
+            else if (paths)
+                rc = render_paths(ctx, w, count, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream);
+            else
+                rc = render_wavefront(ctx, w, count, p->flags, static_cast<float*>(d_slice_sums), static_cast<unsigned long long*>(d_counters), stream);
+            if (rc) return rc;
         }
         HIP_TRY(hipEventRecord(ctx->ev1, stream));
         ctx->timed = true;
@@ -1412,6 +1461,21 @@ int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_s
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
     return resolve_slices(ctx, p, rows, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
+}
+}  // namespace
+
+extern "C" {
+
+int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear,
+                     void* d_counters, void* hip_stream) {
+    return render_device(ctx, p, d_slice_sums, d_resolved, d_linear, d_counters, hip_stream, false);
+}
+
+// rr_render_device for callers that cannot allocate device memory: the same kernels (k_wf_paths, k_wf_accumulate, k_resolve)
+// with their workspace in the file-scope array `scratch` instead of a hipMalloc'ed one.  Calls no hipMalloc / hipFree.
+int rr_render_device_noalloc(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear,
+                             void* d_counters, void* hip_stream) {
+    return render_device(ctx, p, d_slice_sums, d_resolved, d_linear, d_counters, hip_stream, true);
 }
 
 int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uint64_t n, void* hip_stream) {

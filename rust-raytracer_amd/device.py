@@ -104,6 +104,10 @@ class Context:
         """Asynchronous render into caller-owned DEVICE buffers (raw addresses / torch data_ptr())."""
         _check(self._l.rr_render_device(self._h, C.byref(params), d_slice_sums, d_resolved, d_linear, d_counters, stream))
 
+    def render_device_noalloc(self, params, d_slice_sums, d_resolved=None, d_linear=None, d_counters=None, stream=None):
+        """render_device without any device allocation inside the library (static 64 MiB workspace, path-granular kernel)."""
+        _check(self._l.rr_render_device_noalloc(self._h, C.byref(params), d_slice_sums, d_resolved, d_linear, d_counters, stream))
+
     def cast_u8_device(self, d_resolved, d_rgb8, n, stream=None):
         _check(self._l.rr_cast_u8_device(self._h, d_resolved, d_rgb8, n, stream))
 
