@@ -3,23 +3,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one full render pass of the workload (default: the Cornell box of
-src/main.rs:325-368 at 600x600, 1000 samples per pixel, depth 200) with the scene
-already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per
-GPU) every rank renders its own N-th of the sample slices of ONE render_multi call
-with N x the samples (weak scaling: per-GPU work is fixed), and the per-GPU images are
-summed on rank 0 with one RCCL reduce inside the timed region.
+One step = one full render of the workload with the scene already resident in HBM.  The default workload is the
+configuration the throughput target is quoted on: final_scene (src/main.rs:466-541, light repaired as cornell_box
+has it, one moving sphere) at 800x800, 10 000 samples per pixel, depth 50, K = 8 sample slices.  With N > 1
+(launched by torch.distributed.run, one rank per GPU) the ranks share ONE render_multi job:
 
-Rank 0 prints one JSON line.  `value` is whole-job Msamples/s; `roofline` prices the
-path-tracing kernel by its algorithmic bytes; `cpu_baseline` is the CPU oracle
-(oracle/librr_oracle.so, a C++ restatement of the reference: the Rust reference itself
-cannot be built here) timed on this box's host cores on a bounded sample of the same
-workload.
+  --scaling weak   (default) a job of N x the samples in N x the slices: the work per GPU is fixed;
+  --scaling strong the job of one GPU, whatever N: the time per image falls with N;
+  --partition slices|rows|both   how the job is cut: sample slices (summed with one reduce), bands of image
+                   rows (gathered), or both (a reduce per band, a gather over bands).
+
+The combination of the ranks' images (RCCL) and the u8 cast are inside the timed region.  Rank 0 prints one JSON
+line.  `value` is whole-job Msamples/s; `roofline` prices the path-tracing kernels by what they did (tests counted by
+an instrumented pass of the production traversal); `cpu_baseline` is the CPU oracle (oracle/librr_oracle.so, a C++
+restatement of the reference: the Rust reference itself cannot be built here) timed on this box's host cores on a
+bounded sample of the same workload.
 """
 import argparse
-import ctypes as C
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,17 +31,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
-VALU_PEAK_TFLOPS = 157.3    # MI355X peak vector f32 (spec)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak
+VALU_PEAK_TFLOPS = 157.3    # MI355X peak vector f32, counting a fused multiply-add as two operations
 
 WORKLOADS = {
     # name: (scene, width, height, spp, depth): the benchmark configurations
+    "final": ("final", 800, 800, 10000, 50),
     "cornell": ("cornell", 600, 600, 1000, 200),
     "suzanne": ("suzanne", 800, 800, 1000, 100),
-    "final": ("final", 800, 800, 10000, 50),
     "spheres": ("spheres", 400, 225, 100, 50),
-    "mesh": ("mesh", 3840, 2160, 4096, 50),   # 1M-triangle height field + 100k spheres (configs[4]); use --spp for a short run
+    "mesh": ("mesh", 3840, 2160, 4096, 50),   # 1M-triangle height field + 100k spheres; use --spp for a short run
 }
+COUNTER_NAMES = ["samples", "rays", "box_tests", "prim_tests", "inst_visits", "sphere_tests", "rect_tests", "tri_tests",
+                 "machine_lane_steps", "machine_wave_steps"]
 
 
 def host_threads():
@@ -47,46 +53,89 @@ def host_threads():
     return max(1, min(n, cap))
 
 
-def algorithmic_bytes_per_ray(c):
-    """Bytes the reference's algorithm has to read per ray: 32 B per box test, 16 B per sphere,
-    24 B per rect, 48 B per triangle, 16 B per instance/medium visit (counts measured by the
-    instrumented kernel; they are deterministic functions of scene and rays)."""
+def bytes_per_ray(c):
+    """Record bytes per ray for the tests counted in c: 32 B per box test, 16 B per sphere, 24 B per rect, 48 B per
+    triangle, 16 B per instance or medium visit."""
     rays = max(1, c["rays"])
     return (32.0 * c["box_tests"] + 16.0 * c["sphere_tests"] + 24.0 * c["rect_tests"] + 48.0 * c["tri_tests"] +
             16.0 * c["inst_visits"]) / rays
 
 
 def flops_per_ray(c):
+    """f32 operations per ray for the tests counted in c: 20 per box test, 30 per sphere, 15 per rect, 60 per
+    triangle, plus 150 for shading and sampling."""
     rays = max(1, c["rays"])
     return (20.0 * c["box_tests"] + 30.0 * c["sphere_tests"] + 15.0 * c["rect_tests"] + 60.0 * c["tri_tests"]) / rays + 150.0
 
 
+def cpu_info():
+    model, mhz = "unknown", []
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("cpu MHz"):
+                mhz.append(float(line.split(":", 1)[1]))
+    except OSError:
+        pass
+    return model, (round(statistics.median(mhz)) if mhz else None)
+
+
 def cpu_baseline(flat, width, height, depth, seed):
-    """Time the CPU oracle for roughly 10-20 s on this host: one full-image sample slice per thread."""
+    """Time the CPU oracle on this host: one full-image sample slice per thread (render_multi's own decomposition,
+    render.rs:128-151), the process confined to as many cores as it runs threads, median of three runs of a few
+    seconds each on a reduced image of the same scene and camera (throughput per sample does not depend on the
+    image size: the pixels of the small image are a regular subsample of the large one's)."""
     import oracle_lib as O
     threads = host_threads()
+    allowed = sorted(os.sched_getaffinity(0))
+    before = set(allowed)
+    try:
+        os.sched_setaffinity(0, set(allowed[:threads]))  # the oracle's worker threads inherit the mask
+    except OSError:
+        pass
+    w = min(width, 200)
+    h = max(1, min(height, round(height * w / width)))
 
     def timed(spt):
-        p = O.make_params(width, height, threads * spt, n_slices=threads, max_depth=depth, seed=seed)
-        t0 = time.time()
+        p = O.make_params(w, h, threads * spt, n_slices=threads, max_depth=depth, seed=seed)
+        t0 = time.perf_counter()
         r = O.render(flat, p, n_threads=threads, counters=True)
-        return time.time() - t0, r
+        return time.perf_counter() - t0, r
 
-    spt = 1
-    dt, r = timed(spt)
-    rate = width * height * threads / dt
-    want = int(max(1, min(64, round(12.0 * rate / (width * height * threads)))))
-    if want > 1:
-        spt = want
+    dt, r = timed(1)  # calibration (also warms caches and clocks up)
+    spt = int(max(1, min(4096, round(5.0 / max(dt, 1e-3)))))
+    runs = []
+    for _ in range(3):
         dt, r = timed(spt)
-    samples = width * height * threads * spt
+        runs.append((w * h * threads * spt / dt / 1e6, r["counters"]["rays"] / dt / 1e6, dt))
+    try:
+        os.sched_setaffinity(0, before)
+    except OSError:
+        pass
+    runs.sort()
+    med = runs[1]
+    model, mhz = cpu_info()
     return {
-        "value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": f"{width}x{height}, {threads * spt} spp in {threads} slices, depth {depth}: {samples} samples in {dt:.1f} s",
-        "mrays_per_s": round(r["counters"]["rays"] / max(dt, 1e-9) / 1e6, 3),
+        "value": round(med[0], 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"{w}x{h} (the {width}x{height} camera), {threads * spt} spp in {threads} slices, depth {depth}: "
+                  f"{w * h * threads * spt} samples per run, median of 3 runs ({', '.join(f'{x[2]:.1f} s' for x in runs)})",
+        "runs_msamples_per_s": [round(x[0], 4) for x in runs],
+        "mrays_per_s": round(med[1], 3),
+        "cpu_model": model, "cpu_mhz_median": mhz, "confined_to_cpus": allowed[:threads],
         "note": "C++ restatement of the reference (no per-hit Material clones, Box<PDF> allocations or atlas mutex), "
-                "so faster than the Rust binary would be: GPU/CPU ratios against it are conservative",
+                "so faster than the Rust binary would be: GPU/CPU ratios against it are conservative; process confined to "
+                "`cores` CPUs (sched_setaffinity), median of three runs",
     }
+
+
+def latest_profile(pattern):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            return json.load(open(path)), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -94,17 +143,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell", choices=sorted(WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
-    ap.add_argument("--slices", type=int, default=8, help="sample slices per GPU (the reference's n_threads)")
+    ap.add_argument("--workload", default="final", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (of the job under strong scaling, per GPU under weak)")
+    ap.add_argument("--slices", type=int, default=8, help="sample slices K, the reference's n_threads (of the job / per GPU)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--partition", default="slices", choices=["slices", "rows", "both"])
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--flags", type=int, default=0, help="RR_FLAG_* bits for the timed renders (kernel organisation)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting passes")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import rust_raytracer_amd  # noqa: F401
-    from rust_raytracer_amd import device, host, multi
+    from rust_raytracer_amd import abi, device, host, multi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,23 +180,28 @@ def main():
     ctx = device.Context(local_rank)
     info = ctx.upload(flat)
 
-    # One render_multi call with world*K slices and world*spp samples; this rank renders slices
-    # [rank*K, (rank+1)*K): spp samples per pixel per GPU whatever the world size.
-    p = multi.rank_params(W, H, spp, K, depth, args.seed, rank, world)
-    spt = (spp * world) // (K * world)
+    job = multi.job_params(W, H, spp, K, depth, args.seed, world, args.scaling, flags=args.flags)
+    p = multi.rank_share(job, rank, world, args.partition)
+    comb = multi.Combiner(dist, world, args.partition, H)
+    n_sl, rows = p.slice_end - p.slice_begin, p.rows
+    spt = job.samples_per_pixel // job.n_slices
     dev = torch.device("cuda", local_rank)
-    slice_sums = torch.empty((K, H, W, 3), dtype=torch.float32, device=dev)
-    resolved = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    linear = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    slice_sums = torch.empty((max(1, n_sl), rows, W, 3), dtype=torch.float32, device=dev)
+    resolved = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
+    linear = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
     rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    counters = torch.zeros(8, dtype=torch.int64, device=dev)
+    counters = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step(ev=None):
+        if ev:
+            ev[0].record()
         ctx.render_device(p, slice_sums.data_ptr(), resolved.data_ptr(), linear.data_ptr(), counters.data_ptr(), stream)
-        multi.reduce_images(dist, (resolved, linear))
+        if ev:
+            ev[1].record()
+        whole = comb.combine((resolved, linear))
         if rank == 0:
-            ctx.cast_u8_device(resolved.data_ptr(), rgb8.data_ptr(), resolved.numel(), stream)
+            ctx.cast_u8_device(whole[0].data_ptr(), rgb8.data_ptr(), whole[0].numel(), stream)
 
     def barrier():
         if dist is not None:
@@ -155,13 +213,15 @@ def main():
     barrier()
     counters.zero_()
     torch.cuda.synchronize()
-    kernel_ms = []
+    # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the library;
+    # what the library runs on its second stream is ordered inside the bracket by its own events)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(ctx.last_kernel_ms())
+    for i in range(args.steps):
+        step(events[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,86 +234,88 @@ def main():
     counts_rank = counters.cpu().numpy()
 
     if rank == 0:
-        samples_per_step = W * H * spt * K * world
+        samples_per_step = W * H * spt * job.n_slices
         total_samples = int(counts_all[0])
         total_rays = int(counts_all[1])
         assert total_samples == samples_per_step * args.steps, (total_samples, samples_per_step, args.steps)
         value = total_samples / elapsed / 1e6
-
-        # per-ray work of the algorithm, from an instrumented pass outside the timed region: the counting
-        # kernels make every visit the reference makes, which on big BVHs is orders of magnitude more than the
-        # production kernels do, so the pass renders a reduced image (per-ray averages do not depend on it)
-        scale = min(1.0, (2.0e6 / (W * H * K * 4.0)) ** 0.5)
-        Wc, Hc = max(16, int(W * scale)), max(16, int(H * scale))
-        print(f"# counting pass: {Wc}x{Hc}, {K * 4} spp", file=sys.stderr, flush=True)
-        pc = device.make_params(Wc, Hc, K * world * 4, n_slices=K * world, max_depth=depth, seed=args.seed,
-                                slice_begin=0, slice_end=K, flags=1)
-        c2 = torch.zeros(8, dtype=torch.int64, device=dev)
-        ctx.render_device(pc, slice_sums.data_ptr(), None, None, c2.data_ptr(), stream)
-        torch.cuda.synchronize()
-        names = ["samples", "rays", "box_tests", "prim_tests", "inst_visits", "sphere_tests", "rect_tests", "tri_tests"]
-        cdict = dict(zip(names, [int(x) for x in c2.cpu().numpy()]))
-        bpr = algorithmic_bytes_per_ray(cdict)
-        fpr = flops_per_ray(cdict)
         rays_per_launch = int(counts_rank[1]) / args.steps
         samples_per_launch = int(counts_rank[0]) / args.steps
         k_ms = float(np.mean(kernel_ms))
-        # scenes without BVH nodes are one launch of the persistent kernel; scenes with them go through the
-        # wavefront pipeline, whose launches (two per bounce) the HIP events bracket as a whole
-        kernel_name = ("wavefront pipeline: k_wf_init + k_wf_traverse<false> + k_wf_shade (camera rays) + k_wf_finish<false> + k_wf_accumulate"
-                       if info["wavefront"] else "k_wf_paths<false, ...> (persistent kernel at path granularity, counters off) + k_wf_accumulate")
-        alg_bytes = bpr * rays_per_launch + 12.0 * samples_per_launch
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes kept under profiles/ (bytes per sample there, times this launch's samples)
-        traffic = None
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            try:
-                per_sample = json.load(open(path)).get(args.workload, {}).get("hbm_bytes_per_sample")
-            except Exception:
-                per_sample = None
-            if per_sample is not None:
-                traffic = round(per_sample * samples_per_launch)
-                break
-        # measured VALU figures of the same workload from the rocprofv3 PMC passes kept under profiles/
-        measured = {}
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_summary.json")), reverse=True):
-            try:
-                dd = json.load(open(path))["derived"]
-                kk = "k_wf_traverse<false>" if info["wavefront"] else "k_wf_paths<false>"
-                measured = {"kernel": kk, "valu_busy_pct_largest_dispatch": dd.get("VALUBusy_first_dispatch", {}).get(kk),
-                            "valu_lane_utilization_pct_largest_dispatch": dd.get("VALUUtilization_first_dispatch", {}).get(kk),
-                            "waves_per_cu_largest_dispatch": dd.get("MeanOccupancyPerCU_first_dispatch", {}).get(kk),
-                            "active_lanes_per_valu_inst": dd.get("active_lanes_per_valu_inst"),
-                            "valu_insts_per_wave_ray": dd.get("valu_insts_per_wave_ray"), "source": os.path.basename(path)}
-            except Exception:
-                measured = {}
-            break
+        if args.flags & abi.FLAG_PERSISTENT:
+            kernel_name = "k_render (item-granular persistent kernel)"
+        elif (args.flags & abi.FLAG_WAVEFRONT) or (info["wavefront"] and not (args.flags & abi.FLAG_PATHS)):
+            kernel_name = "wavefront pipeline: k_wf_init + k_wf_traverse + k_wf_shade (camera rays) + k_wf_finish + k_wf_accumulate"
+        else:
+            kernel_name = "k_wf_paths (persistent kernel at path granularity) + k_wf_accumulate"
+
+        # What the kernels did per ray, from instrumented passes outside the timed region on a reduced image (per-ray
+        # averages do not depend on the image size): `production` counts the tests of the traversal the timed kernels run
+        # (redundant visits skipped, subtrees culled); `reference_order` counts every visit the reference's algorithm makes.
+        per_ray = {}
+        if not args.no_count:
+            scale = min(1.0, (2.0e6 / (W * H * K * 4.0)) ** 0.5)
+            Wc, Hc = max(16, int(W * scale)), max(16, int(H * scale))
+            for label, flag in (("production", abi.FLAG_COUNT_PRODUCTION), ("reference_order", abi.FLAG_COUNTERS)):
+                pc = device.make_params(Wc, Hc, K * 4, n_slices=K, max_depth=depth, seed=args.seed,
+                                        flags=flag | (args.flags & (abi.FLAG_PERSISTENT | abi.FLAG_WAVEFRONT | abi.FLAG_PATHS)))
+                c2 = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=dev)
+                cs = torch.empty((K, Hc, Wc, 3), dtype=torch.float32, device=dev)
+                ctx.render_device(pc, cs.data_ptr(), None, None, c2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                per_ray[label] = dict(zip(COUNTER_NAMES, [int(x) for x in c2.cpu().numpy()]))
+            print(f"# counting passes: {Wc}x{Hc}, {K * 4} spp", file=sys.stderr, flush=True)
+        prod = per_ray.get("production")
+        roofline = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                    "kernel": kernel_name, "kernel_ms": round(k_ms, 3), "rays_per_launch": int(rays_per_launch)}
+        if prod:
+            fpr, bpr = flops_per_ray(prod), bytes_per_ray(prod)
+            achieved = fpr * rays_per_launch / (k_ms * 1e-3) / 1e12
+            ref = per_ray["reference_order"]
+            rays_c = max(1, prod["rays"])
+            roofline.update({
+                "achieved": round(achieved, 3), "frac": round(achieved / VALU_PEAK_TFLOPS, 5),
+                "peak_without_fma": VALU_PEAK_TFLOPS / 2, "frac_of_peak_without_fma": round(2 * achieved / VALU_PEAK_TFLOPS, 5),
+                "flops_per_ray": round(fpr, 1),
+                "per_ray_production": {k: round(prod[k] / rays_c, 3) for k in COUNTER_NAMES[2:8]},
+                "per_ray_reference_order": {k: round(ref[k] / max(1, ref["rays"]), 3) for k in COUNTER_NAMES[2:8]},
+                "machine_lanes_at_work": (round(prod["machine_lane_steps"] / max(1, prod["machine_wave_steps"]), 2)
+                                          if prod["machine_wave_steps"] else None),
+                "record_bytes_per_ray": round(bpr, 1),
+                "record_gbs": round((bpr * rays_per_launch + 12.0 * samples_per_launch) / (k_ms * 1e-3) / 1e9, 1),
+                "note": "bound = vector ALU issue: the scene records are cache-resident (scalar cache / L2; `record_gbs` is the "
+                        "rate at which the kernels consume record bytes, served by caches, not HBM: see traffic and hbm_frac). "
+                        "achieved = flops_per_ray (20/box test, 30/sphere, 15/rect, 60/triangle, +150 shading; tests counted on the "
+                        "production traversal) x rays per launch / kernel time.  The parity contract forbids fused multiply-add "
+                        "(-ffp-contract=off), so the attainable peak is peak_without_fma."})
+        # HBM bytes per launch and VALU issue figures from the rocprofv3 PMC passes of the same workload kept under profiles/
+        tr, tr_src = latest_profile("r*_pmc_traffic.json")
+        if tr and tr.get(args.workload, {}).get("hbm_bytes_per_sample") is not None:
+            traffic = tr[args.workload]["hbm_bytes_per_sample"] * samples_per_launch
+            roofline["traffic"] = round(traffic)
+            roofline["hbm_frac"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roofline["traffic_source"] = tr_src
+        summ, summ_src = latest_profile(f"r*_{args.workload}_summary.json")
+        if summ:
+            dd = summ.get("derived", {})
+            roofline["measured"] = {k: dd.get(k) for k in ("kernel", "valu_issue_slot_frac", "active_lanes_per_valu_inst",
+                                                          "valu_insts_per_wave_ray", "salu_insts_per_wave_ray", "waves_per_cu",
+                                                          "lane_slot_frac") if k in dd}
+            roofline["measured"]["source"] = summ_src
         out = {
             "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {W}x{H}, {spp} spp per GPU in {K} slices per GPU, depth {depth}",
-                       "scene": scene_name, "width": W, "height": H, "spp_per_gpu": spp, "slices_per_gpu": K,
-                       "max_depth": depth, "parallelism": f"sample-slices x{world}", "seed": args.seed,
-                       "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {W}x{H}, {job.samples_per_pixel} spp in {job.n_slices} slices, depth {depth}"
+                                   + (f" ({spp} spp in {K} slices per GPU)" if args.scaling == "weak" and world > 1 else ""),
+                       "scene": scene_name, "width": W, "height": H, "spp": job.samples_per_pixel, "slices": job.n_slices,
+                       "max_depth": depth, "parallelism": f"{args.partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)",
+                       "seed": args.seed, "flags": args.flags, "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
             "rays_per_sample": round(total_rays / max(1, total_samples), 4),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": kernel_name, "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_ray": round(bpr, 2), "rays_per_launch": int(rays_per_launch),
-                         "per_ray": {k: round(cdict[k] / max(1, cdict["rays"]), 3) for k in names[2:]},
-                         "note": "algorithmic bytes = records the reference's algorithm reads per ray (counted in its visit order); "
-                                 "the scenes are cache-resident (Cornell: 2.4 KB, read through the scalar cache), so these bytes are "
-                                 "not HBM traffic (see traffic) and frac can exceed 1; the kernels are VALU-bound (see valu)"},
-            "valu": {"flops_per_ray": round(fpr, 1), "achieved_tflops": round(fpr * rays_per_launch / (k_ms * 1e-3) / 1e12, 3),
-                     "peak_tflops": VALU_PEAK_TFLOPS, "measured": measured,
-                     "frac": round(fpr * rays_per_launch / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
-                     "note": "flops_per_ray prices the tests the reference's algorithm makes per ray (counted in its visit order); the "
-                             "production kernels skip visits that provably cannot change the result, so on BVH scenes frac can exceed 1; "
-                             "what the VALUs actually did is under measured"},
-            "reference_published": {"msamples_per_s": 0.67, "source": "src/notes.txt:1-5 (600x600, 200 spp, depth 200, unknown CPU)"},
+            "kernel_ms_per_step": [round(x, 3) for x in kernel_ms],
+            "roofline": roofline,
+            "reference_published": {"msamples_per_s": 0.67, "source": "src/notes.txt:1-5 (Cornell box 600x600, 200 spp, depth 200, unknown CPU)"},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(flat, W, H, depth, args.seed)

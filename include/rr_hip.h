@@ -231,7 +231,7 @@ typedef struct rr_render_params {
                                     (row_end-row_begin) x width x 3, and bands are contiguous in the image.   */
 } rr_render_params;
 
-#define RR_FLAG_COUNTERS 1u /* also count box tests / primitive tests; this build of the kernels makes
+#define RR_FLAG_COUNTERS 1u /* count box tests / primitive tests (rr_counters); this build of the kernels makes
                                every BVH visit the reference makes, in its order (slower, same image) */
 /* The library renders with one of three kernel organisations that produce the same bits.  The default is a
  * persistent kernel whose lanes follow single paths from camera ray to termination and leave the sample
@@ -248,6 +248,10 @@ typedef struct rr_render_params {
 #define RR_FLAG_NO_FINISH_KERNEL 8u
 /* Forces the path-granular persistent kernel (the default of most scenes) for any scene. */
 #define RR_FLAG_PATHS 16u
+/* Count what the production kernels do: the same traversal as without flags (redundant BVH visits skipped,
+ * subtrees culled), with the counters of rr_counters switched on.  Excludes RR_FLAG_COUNTERS, whose build of
+ * the kernels makes (and counts) every visit of the reference instead.  Same image as either.           */
+#define RR_FLAG_COUNT_PRODUCTION 32u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */
@@ -258,6 +262,10 @@ typedef struct rr_counters {
     uint64_t sphere_tests; /* of prim_tests: spheres and moving spheres                   */
     uint64_t rect_tests;   /* of prim_tests: rects (cuboid sides included)                */
     uint64_t tri_tests;    /* of prim_tests: triangles                                    */
+    uint64_t machine_lane_steps; /* steps of the per-lane BVH traversal machine, summed over lanes: a lane with a
+                                    subtree to walk takes one step per wave step           (both counting flags) */
+    uint64_t machine_wave_steps; /* steps the waves took while any of their lanes walked a subtree; lane_steps /
+                                    (64 * wave_steps) is the fraction of lanes at work inside the BVHs          */
 } rr_counters;
 
 typedef struct rr_hit {

@@ -23,6 +23,8 @@ FLAG_PERSISTENT = 2
 FLAG_WAVEFRONT = 4
 FLAG_NO_FINISH_KERNEL = 8
 FLAG_PATHS = 16
+FLAG_COUNT_PRODUCTION = 32
+N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
 
@@ -134,7 +136,8 @@ class RenderParams(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("samples", u64), ("rays", u64), ("box_tests", u64), ("prim_tests", u64), ("inst_visits", u64),
-                ("sphere_tests", u64), ("rect_tests", u64), ("tri_tests", u64)]
+                ("sphere_tests", u64), ("rect_tests", u64), ("tri_tests", u64),
+                ("machine_lane_steps", u64), ("machine_wave_steps", u64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

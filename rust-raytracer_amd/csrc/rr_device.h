@@ -113,7 +113,11 @@ struct DevScene {  // kernel argument
 
 struct Counts {
     uint32_t rays, box_tests, sphere_tests, rect_tests, tri_tests, inst_visits, samples;
+    uint32_t lane_steps, wave_steps;  // steps of the per-lane traversal machine: (lane, step) pairs that moved; steps of the wave (counted on one lane)
 };
+// Counting builds of the kernels (template parameter COUNT): COUNT_REFERENCE makes every BVH visit the reference makes,
+// in its order, and counts them; COUNT_PRODUCTION counts what the production traversal (visit skipping, culling) does.
+constexpr int COUNT_OFF = 0, COUNT_REFERENCE = 1, COUNT_PRODUCTION = 2;
 
 // ------------------------------------------------------------------ math
 struct f3 {
@@ -469,7 +473,7 @@ struct Trav {
 __device__ __forceinline__ bool trav_at_node(const Trav& m) { return m.node != NONE && dtag(m.node) == RR_TAG_BVH; }
 __device__ __forceinline__ bool trav_at_leaf(const Trav& m) { return m.node != NONE && dtag(m.node) != RR_TAG_BVH; }
 
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ BVH node
     if (m.node != NONE && dtag(m.node) == RR_TAG_BVH) {
@@ -477,7 +481,7 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
         const float4 q0 = sc.bvh[2 * idx], q1 = sc.bvh[2 * idx + 1];
         m.node = NONE;
         const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
-        const uint32_t cls = COUNT ? (dextra(right) != BVH_CLASS_NO_BOX ? BVH_CLASS_REFERENCE : BVH_CLASS_NO_BOX) : dextra(right);
+        const uint32_t cls = COUNT == COUNT_REFERENCE ? (dextra(right) != BVH_CLASS_NO_BOX ? BVH_CLASS_REFERENCE : BVH_CLASS_NO_BOX) : dextra(right);
         bool pass = true;
         if (cls != BVH_CLASS_NO_BOX) {
             if (COUNT) cnt.box_tests++;
@@ -516,7 +520,7 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
             const uint32_t l = left & REF_MASK, r = right & REF_MASK;
             const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
             // In the culling classes evaluating the same child twice over the same or a smaller
-            // range cannot change the outcome.  The counting build evaluates everything.
+            // range cannot change the outcome.  The reference-order counting build evaluates everything.
             const bool pure = cls >= BVH_CLASS_CULL_RANGE;
             if (pure && l == r) {
                 m.node = l;  // span-1 node: the second visit repeats the first
@@ -537,7 +541,7 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
     }
 }
 
-template <bool COUNT, class World>
+template <int COUNT, class World>
 __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const World& world, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ primitive, list, instance or medium
     if (m.node != NONE && dtag(m.node) != RR_TAG_BVH) {
@@ -648,7 +652,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
     }
 }
 
-template <bool COUNT, class World, class Draw>
+template <int COUNT, class World, class Draw>
 __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk, uint32_t stride,
                                          Counts& cnt) {
     // ------------------------------------------- return to the callers
@@ -732,7 +736,7 @@ __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const Worl
 
 // One step of a single lane's sequence: a node if the lane is at one, then whatever it is at
 // after that, then the returns.
-template <bool COUNT, class World, class Draw>
+template <int COUNT, class World, class Draw>
 __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk,
                                           uint32_t stride, Counts& cnt) {
     trav_node<COUNT>(sc, m, stk, stride, cnt);
@@ -752,13 +756,14 @@ struct WorldInRegs {
 };
 
 // The whole recursive call for `start`, to completion.
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 wo, f3 wd, f3 o, f3 d, float time, float tmin,
                                         float& tmax_io, uint32_t& cur_io, Rng& rng, uint32_t* stk, uint32_t stride, Counts& cnt) {
     Trav m;
     m.begin(start, o, d, tmin, tmax_io, cur_io);
     const WorldInRegs world{wo, wd, time};
     do {
+        if (COUNT) cnt.lane_steps++;
         trav_step<COUNT>(sc, m, world, rng, stk, stride, cnt);
     } while (!m.finished());
     tmax_io = m.tmax;
@@ -774,7 +779,7 @@ __device__ __forceinline__ void machine(const DevScene& sc, uint32_t start, f3 w
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Primitive or cuboid named by the wave-uniform ref `n`, against the lanes' rays.
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, f3 d, float time, float tmin, float& tmax,
                                           uint32_t& cur, Counts& cnt) {
     const uint32_t tag = dtag(n), idx = didx(n);
@@ -845,7 +850,7 @@ struct Op {
 // probe missed, until that medium's end op.
 // VEC = false builds an interpreter for programs without OP_LEAF_REF and OP_SUBTREE (scenes made of rects,
 // spheres, cuboids, instances and media of those): no vector memory access, no traversal machine.
-template <bool COUNT, bool VEC = true>
+template <int COUNT, bool VEC = true>
 __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float time, float tmin, float tmax, bool enabled,
                                          Rng& rng, uint32_t* stk, uint32_t stride, float& t_hit, uint32_t& ref_hit, Counts& cnt) {
     // `enabled` is false for lanes that only ride along (the caller keeps this call in wave-uniform
@@ -990,7 +995,7 @@ struct ProgState {
 // `park_below`: lanes still descending are parked once fewer than this many are left (0: never park), but not
 // before `min_steps` machine steps have been taken in this visit, so that parked lanes always make progress.
 // On return a lane with s.parked set has no result yet; the others have theirs in (s.tmax, s.cur).
-template <bool COUNT>
+template <int COUNT>
 __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, bool enabled, ProgState& s, Rng& rng,
                                                  uint32_t* stk, uint32_t stride, uint32_t park_below, uint32_t min_steps, Counts& cnt) {
     bool act = enabled && !s.parked;  // the lane executes the ops it comes to
@@ -1016,6 +1021,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
                 if (n == 0 || (n < park_below && steps >= min_steps)) break;
                 if (going) trav_step<COUNT>(sc, s.m, world, rng, stk, stride, cnt);
+                if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
             if (in) {

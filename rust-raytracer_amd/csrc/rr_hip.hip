@@ -51,9 +51,10 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* counters) {
     if (!counters) return;
-    unsigned long long v[8] = {c.samples, c.rays, c.box_tests, (unsigned long long)c.sphere_tests + c.rect_tests + c.tri_tests, c.inst_visits, c.sphere_tests, c.rect_tests, c.tri_tests};
+    unsigned long long v[10] = {c.samples, c.rays, c.box_tests, (unsigned long long)c.sphere_tests + c.rect_tests + c.tri_tests, c.inst_visits, c.sphere_tests, c.rect_tests, c.tri_tests,
+                                c.lane_steps, c.wave_steps};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 10; ++i) {
         unsigned long long s = wave_sum(v[i]);
         if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&counters[i], s);
     }
@@ -62,7 +63,7 @@ __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long
 #ifndef RR_RENDER_CHUNK
 #define RR_RENDER_CHUNK 64u  // work items a wave claims at a time
 #endif
-template <bool COUNT, bool VEC>
+template <int COUNT, bool VEC>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevScene sc, RenderArgs a, float* __restrict__ slice_sums,
                                                 unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
     // fifth of the wave slots of the Cornell box render).  A chunk is 64 consecutive items, one 8x8 tile of one slice.
     uint64_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
 
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool have_item = false, path_active = false;
     uint32_t px = 0, py = 0, sl = 0, s = 0;
     f3 acc = mk3(0.f, 0.f, 0.f);
@@ -198,10 +199,10 @@ __global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, c
     const float time = r[6];
     Rng g;
     g.start(seed, i, 0, 0);
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     float t;
     uint32_t ref;
-    traverse<false>(sc, o, d, time, t_min, t_max, true, g, stk, blockDim.x, t, ref, cnt);
+    traverse<COUNT_OFF>(sc, o, d, time, t_min, t_max, true, g, stk, blockDim.x, t, ref, cnt);
     float* of = out_f + static_cast<uint64_t>(i) * 12u;
     out_ref[i] = ref;
     if (ref == NONE) {
@@ -734,7 +735,7 @@ int resolve_slices(rr_context* ctx, const rr_render_params* p, uint32_t rows, ui
 // launch that runs the remaining paths to their ends, and the in-order accumulation of the batch.
 // Everything is enqueued; the function does not wait for the device (except under
 // RR_FLAG_NO_FINISH_KERNEL, where the host has to learn when the last path has ended).
-int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, float* sums, unsigned long long* counters, hipStream_t stream) {
+int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float* sums, unsigned long long* counters, hipStream_t stream) {
     // Batch size: as many samples per slot as fit the workspace budget (80 bytes per path).  Two workspaces
     // take turns: the last paths of a batch (whose bounces each last as long as their slowest ray while the
     // chip idles) and its accumulation run on a second stream beside the next batch's bounce loop.
@@ -786,13 +787,17 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
     }
 
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
-    const void* kernel = count ? reinterpret_cast<const void*>(&k_wf_traverse<true>) : reinterpret_cast<const void*>(&k_wf_traverse<false>);
+    using TraverseKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, uint32_t, unsigned long long*);
+    using FinishKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, unsigned long long*);
+    const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? k_wf_traverse<COUNT_PRODUCTION>
+                                      : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE> : k_wf_traverse<COUNT_OFF>;
+    const FinishKernel k_finish = count == COUNT_PRODUCTION ? k_wf_finish<COUNT_PRODUCTION>
+                                  : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE> : k_wf_finish<COUNT_OFF>;
     int grid_full = 0;
-    if (int rc = launch_dims(ctx, lds, kernel, &grid_full)) return rc;
+    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_traverse), &grid_full)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
     int grid_finish = 0;
-    if (int rc = launch_dims(ctx, lds, count ? reinterpret_cast<const void*>(&k_wf_finish<true>) : reinterpret_cast<const void*>(&k_wf_finish<false>), &grid_finish))
-        return rc;
+    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_finish), &grid_finish)) return rc;
     hipStream_t aux = ctx->wf_aux;
 
     // A batch takes its camera rays as one pair of launches over the queue of all its paths, then one launch of
@@ -843,10 +848,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
                 const uint32_t live_blocks = (live + 255u) / 256u;
                 const uint32_t grid_t = std::min<uint32_t>(static_cast<uint32_t>(grid_full), live_blocks);
                 const uint32_t grid_s = std::min<uint32_t>(live_blocks, static_cast<uint32_t>(ctx->n_cus) * 16u);
-                if (count)
-                    hipLaunchKernelGGL(k_wf_traverse<true>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
-                else
-                    hipLaunchKernelGGL(k_wf_traverse<false>, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
+                hipLaunchKernelGGL(k_traverse, dim3(grid_t), dim3(256), lds, stream, ctx->sc, a, st, q_in, c_in, ctx->root, counters);
                 hipLaunchKernelGGL(k_wf_shade, dim3(grid_s), dim3(256), 0, stream, ctx->sc, a, st, q_in, c_in, q_out, c_out, c_clear, counters);
                 HIP_TRY(hipGetLastError());
                 if (poll && it >= POLL_FROM && it != a.max_depth) {
@@ -865,10 +867,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
             // (a wave that finds the queue empty leaves at once)
             const uint32_t grid_f = std::min<uint32_t>((finish_bound + 256u * RR_WF_FINISH_PATHS_PER_LANE - 1u) / (256u * RR_WF_FINISH_PATHS_PER_LANE),
                                                        static_cast<uint32_t>(grid_finish));
-            if (count)
-                hipLaunchKernelGGL(k_wf_finish<true>, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, counters);
-            else
-                hipLaunchKernelGGL(k_wf_finish<false>, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, counters);
+            hipLaunchKernelGGL(k_finish, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, counters);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, aux, a, st, sums);
@@ -887,7 +886,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, bool count, uint32_t flags, floa
 // The persistent renderer at path granularity: batches of samples of every slot, each one launch of k_wf_paths that
 // leaves every sample's value in `values` (room for `capacity` paths), and the in-order accumulation of the batch.
 // Allocates nothing: the caller brings the values' memory and the device word the waves claim their paths from.
-int render_paths_in(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream, float4* values,
+int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned long long* counters, hipStream_t stream, float4* values,
                     uint64_t capacity, unsigned int* next_path) {
     const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, capacity / a.n_slots);
     if (most == 0) return fail(RR_E_LIMIT, "render_paths: the sample values of one sample per (slice, pixel) do not fit the workspace");
@@ -895,9 +894,12 @@ int render_paths_in(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned
     WfState st{};
     st.thr = values;
     using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
-    const PathsKernel kernel = ctx->has_subtrees ? (count ? k_wf_paths<true, true, true> : k_wf_paths<false, true, true>)
-                               : ctx->prog_vector_ops ? (count ? k_wf_paths<true, true> : k_wf_paths<false, true>)
-                                                      : (count ? k_wf_paths<true, false> : k_wf_paths<false, false>);
+    // (a scene without BVH nodes has no visits to skip: its two counting modes are one kernel)
+    const PathsKernel kernel =
+        ctx->has_subtrees ? (count == COUNT_PRODUCTION  ? k_wf_paths<COUNT_PRODUCTION, true, true>
+                             : count == COUNT_REFERENCE ? k_wf_paths<COUNT_REFERENCE, true, true> : k_wf_paths<COUNT_OFF, true, true>)
+        : ctx->prog_vector_ops ? (count ? k_wf_paths<COUNT_REFERENCE, true> : k_wf_paths<COUNT_OFF, true>)
+                               : (count ? k_wf_paths<COUNT_REFERENCE, false> : k_wf_paths<COUNT_OFF, false>);
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     int grid = 0;
     if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
@@ -920,7 +922,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned
 
 // render_paths_in with the context's grow-only workspace: as many samples per slot in flight as min(16 GiB, a quarter of
 // free HBM) holds.
-int render_paths(rr_context* ctx, WfArgs a, bool count, float* sums, unsigned long long* counters, hipStream_t stream) {
+int render_paths(rr_context* ctx, WfArgs a, int count, float* sums, unsigned long long* counters, hipStream_t stream) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
@@ -1367,7 +1369,9 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const uint32_t n_sl = p->slice_end - p->slice_begin;
     const uint32_t spt = p->samples_per_pixel / p->n_slices;
-    const bool count = (p->flags & RR_FLAG_COUNTERS) != 0;
+    if ((p->flags & RR_FLAG_COUNTERS) && (p->flags & RR_FLAG_COUNT_PRODUCTION))
+        return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_COUNTERS and RR_FLAG_COUNT_PRODUCTION exclude each other");
+    const int count = (p->flags & RR_FLAG_COUNTERS) ? COUNT_REFERENCE : (p->flags & RR_FLAG_COUNT_PRODUCTION) ? COUNT_PRODUCTION : COUNT_OFF;
     if (((p->flags & RR_FLAG_PERSISTENT) != 0) + ((p->flags & RR_FLAG_WAVEFRONT) != 0) + ((p->flags & RR_FLAG_PATHS) != 0) > 1)
         return fail(RR_E_INVALID, "rr_render_device: RR_FLAG_PERSISTENT, RR_FLAG_WAVEFRONT and RR_FLAG_PATHS exclude each other");
     // the persistent kernel at path granularity (k_wf_paths) unless the scene is one for the pipeline or a flag asks for something else
@@ -1422,8 +1426,10 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
         return resolve_slices(ctx, p, rows, n_sl, spt, d_slice_sums, d_resolved, d_linear, stream);
     }
     using RenderKernel = void (*)(DevScene, RenderArgs, float*, unsigned long long*);
-    const RenderKernel render_kernel = ctx->prog_vector_ops ? (count ? k_render<true, true> : k_render<false, true>)
-                                                            : (count ? k_render<true, false> : k_render<false, false>);
+    const RenderKernel render_kernel =
+        ctx->prog_vector_ops ? (count == COUNT_PRODUCTION  ? k_render<COUNT_PRODUCTION, true>
+                                : count == COUNT_REFERENCE ? k_render<COUNT_REFERENCE, true> : k_render<COUNT_OFF, true>)
+                             : (count ? k_render<COUNT_REFERENCE, false> : k_render<COUNT_OFF, false>);
     const void* kernel = reinterpret_cast<const void*>(render_kernel);
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     int grid = 0;

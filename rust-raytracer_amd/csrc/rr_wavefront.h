@@ -136,13 +136,13 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-template <bool COUNT, bool VEC, bool PARK = false>
+template <int COUNT, bool VEC, bool PARK = false>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
     bool exhausted = a.n_paths == 0;        // wave-uniform: no unclaimed paths are left for anyone
     bool path_active = false;
@@ -274,7 +274,7 @@ struct WfDraw {
     }
 };
 
-template <bool COUNT>
+template <int COUNT>
 __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     k_wf_traverse(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
                   unsigned long long* counters) {
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     uint32_t* stk = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
     const uint32_t total = ctl->count;
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     Trav m;
     m.begin(NONE, mk3(0.f, 0.f, 0.f), mk3(1.f, 1.f, 1.f), 0.f, 0.f, NONE);
     bool active = false;
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
         // waiting would only idle them; returns are taken as they come.
         const WfWorld world{st, p};
         WfDraw draw{st, a, p, draws};
+        if (COUNT) cnt.lane_steps += active ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
         if (active) trav_node<COUNT>(sc, m, stk, stride, cnt);
         const bool at_leaf = active && trav_at_leaf(m);
         const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
                                                   unsigned long long* counters) {
     const uint32_t total = ctl_in->count;
     const uint32_t step = gridDim.x * blockDim.x;
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     // Paths that go on are collected per wave in LDS and appended to the next queue a batch at a time:
     // one atomic on the shared counter per WF_STAGE-64 or more entries instead of one per wave iteration.
     __shared__ uint32_t stage_all[4][WF_STAGE];
@@ -474,14 +475,14 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 // path, and the queue is claimed a chunk at a time per wave as in k_wf_traverse.  (Letting the lanes of a
 // wave run out of step as well — traversal moves, shading and refills whenever enough lanes wait for one —
 // was measured equal on the Suzanne scene and 4-10 % slower on final_scene.)
-template <bool COUNT>
+template <int COUNT>
 __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
                                                                                 WfCtl* ctl, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
     const uint32_t total = ctl->count;
-    Counts cnt = {0, 0, 0, 0, 0, 0, 0};
+    Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t n_waves = gridDim.x * (blockDim.x / 64u);
     const uint32_t chunk = min(max(total / (n_waves * 8u), 16u), 1024u);
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk

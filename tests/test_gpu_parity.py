@@ -21,6 +21,12 @@ pytestmark = pytest.mark.gpu
 CONFIG_SCENES = {}
 
 
+def counts(r):
+    """The counters of a render that do not depend on how the kernels organise their work (the steps of the per-lane
+    traversal machine do: the wavefront pipeline walks the whole tree with it, the persistent kernels only the BVHs)."""
+    return {k: v for k, v in r["counters"].items() if not k.startswith("machine_")}
+
+
 def config_scene(name):
     if name not in CONFIG_SCENES:
         CONFIG_SCENES[name] = host.build_config_scene(name)
@@ -337,6 +343,38 @@ def test_intersection_counters_match_oracle(gpu_ctx):
 
 
 @pytest.mark.parametrize("name", ["cornell", "spheres", "suzanne", "final"])
+def test_production_counters_count_the_production_traversal(gpu_ctx, name):
+    """RR_FLAG_COUNT_PRODUCTION switches the counters on without changing the traversal: same image as without flags,
+    the same counts from every kernel organisation, never more tests than the reference-order count, and far fewer box
+    tests wherever BVH subtrees are culled."""
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=2, max_depth=30, seed=29)
+    plain = gpu_ctx.render(device.make_params(60, 44, 6, **kw))
+    prod = gpu_ctx.render(device.make_params(60, 44, 6, flags=abi.FLAG_COUNT_PRODUCTION, **kw))
+    ref = gpu_ctx.render(device.make_params(60, 44, 6, flags=abi.FLAG_COUNTERS, **kw))
+    assert np.array_equal(plain["slice_sums"], prod["slice_sums"], equal_nan=True)
+    cp, cr = prod["counters"], ref["counters"]
+    assert cp["rays"] == cr["rays"] == plain["counters"]["rays"] and cp["samples"] == 60 * 44 * 6
+    assert plain["counters"]["box_tests"] == plain["counters"]["prim_tests"] == 0  # counters are off without a flag
+    for k in ("box_tests", "sphere_tests", "rect_tests", "tri_tests", "prim_tests"):
+        assert cp[k] <= cr[k], k
+    assert cp["inst_visits"] == cr["inst_visits"] or flat.n_media > 0
+    assert cp["prim_tests"] == cp["sphere_tests"] + cp["rect_tests"] + cp["tri_tests"]
+    if flat.n_bvh_nodes:
+        assert 0 < cp["box_tests"] < 0.7 * cr["box_tests"]
+        assert 0 < cp["machine_lane_steps"] <= 64 * cp["machine_wave_steps"]
+    else:
+        assert counts(prod) == counts(ref) and cp["machine_lane_steps"] == 0
+    for flags in (abi.FLAG_PATHS, abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT):
+        other = gpu_ctx.render(device.make_params(60, 44, 6, flags=flags | abi.FLAG_COUNT_PRODUCTION, **kw))
+        assert np.array_equal(plain["slice_sums"], other["slice_sums"], equal_nan=True)
+        assert counts(other) == counts(prod), flags
+    with pytest.raises(device.DeviceError, match="exclude"):
+        gpu_ctx.render(device.make_params(8, 8, 2, flags=abi.FLAG_COUNTERS | abi.FLAG_COUNT_PRODUCTION))
+
+
+@pytest.mark.parametrize("name", ["cornell", "spheres", "suzanne", "final"])
 def test_fast_traversal_equals_reference_order_traversal(gpu_ctx, name):
     """The production kernel leaves out BVH visits that cannot change the result (the re-test of `left`
     after it missed, collider.rs:555-561, and the second visit of a span-1 node's only child) wherever
@@ -363,10 +401,10 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT | extra | wf_extra, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
-        assert one["counters"] == two["counters"]
+        assert counts(one) == counts(two)
         for flags in (extra, abi.FLAG_PATHS | extra):  # whichever organisation the library picks; the path-granular kernel
             third = gpu_ctx.render(device.make_params(45, 37, 9, flags=flags, **kw))
-            assert np.array_equal(one["slice_sums"], third["slice_sums"], equal_nan=True) and one["counters"] == third["counters"]
+            assert np.array_equal(one["slice_sums"], third["slice_sums"], equal_nan=True) and counts(one) == counts(third)
     # a slice range, a sample offset and zero depth go through the same bookkeeping
     for kw2 in (dict(slice_begin=1, slice_end=3), dict(sample_offset=40), dict(max_depth=0), dict(max_depth=1)):
         args = dict(kw)
@@ -374,9 +412,9 @@ def test_wavefront_pipeline_equals_persistent_kernel(gpu_ctx, name):
         one = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_PERSISTENT, **args))
         two = gpu_ctx.render(device.make_params(45, 37, 9, flags=abi.FLAG_WAVEFRONT, **args))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True), kw2
-        assert one["counters"] == two["counters"]
+        assert counts(one) == counts(two)
         auto = gpu_ctx.render(device.make_params(45, 37, 9, **args))
-        assert np.array_equal(one["slice_sums"], auto["slice_sums"], equal_nan=True) and one["counters"] == auto["counters"], kw2
+        assert np.array_equal(one["slice_sums"], auto["slice_sums"], equal_nan=True) and counts(one) == counts(auto), kw2
 
 
 def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch):
@@ -391,7 +429,7 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
     for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_PATHS):
         two = gpu_ctx.render(device.make_params(40, 32, 46, flags=flags, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
-        assert one["counters"] == two["counters"]
+        assert counts(one) == counts(two)
 
 
 def test_path_granular_kernel_equals_item_granular_kernel(gpu_ctx, monkeypatch):
@@ -408,14 +446,14 @@ def test_path_granular_kernel_equals_item_granular_kernel(gpu_ctx, monkeypatch):
         one = gpu_ctx.render(device.make_params(53, 41, 14, flags=abi.FLAG_PERSISTENT | flags, **args))
         two = gpu_ctx.render(device.make_params(53, 41, 14, flags=flags, **args))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True), extra
-        assert np.array_equal(one["rgb8"], two["rgb8"]) and one["counters"] == two["counters"], extra
+        assert np.array_equal(one["rgb8"], two["rgb8"]) and counts(one) == counts(two), extra
     one = gpu_ctx.render(device.make_params(53, 41, 2, flags=abi.FLAG_PERSISTENT, **kw))  # fewer samples than slices: none are taken
     two = gpu_ctx.render(device.make_params(53, 41, 2, **kw))
     assert np.array_equal(one["slice_sums"], two["slice_sums"]) and two["counters"]["samples"] == 0
     one = gpu_ctx.render(device.make_params(53, 41, 60, flags=abi.FLAG_PERSISTENT, **kw))
     monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(16 * 3 * 53 * 41 * 3))  # three samples per slot and batch: 7 batches of 20
     two = gpu_ctx.render(device.make_params(53, 41, 60, **kw))
-    assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True) and one["counters"] == two["counters"]
+    assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True) and counts(one) == counts(two)
 
 
 @pytest.mark.parametrize("name,side,spp", [("suzanne", 640, 96), ("final", 512, 136)])
@@ -431,7 +469,7 @@ def test_wavefront_large_batch_equals_persistent_kernel(gpu_ctx, name, side, spp
         two = gpu_ctx.render(device.make_params(side, side, spp, flags=flags, **kw))
         assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
         assert np.array_equal(one["rgb8"], two["rgb8"])
-        assert one["counters"] == two["counters"]
+        assert counts(one) == counts(two)
 
 
 # --------------------------------------------------- size-independent properties

@@ -19,7 +19,7 @@ def _both(ctx, p):
         sums = torch.full((k, h, w, 3), -7.0, dtype=torch.float32, device=dev)
         resolved = torch.full((h, w, 3), -7.0, dtype=torch.float32, device=dev)
         linear = torch.full((h, w, 3), -7.0, dtype=torch.float32, device=dev)
-        counters = torch.zeros(8, dtype=torch.int64, device=dev)
+        counters = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         fn(p, sums.data_ptr(), resolved.data_ptr(), linear.data_ptr(), counters.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
