@@ -1003,6 +1003,12 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
     Op next = prog[0];
     uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
     const WorldInRegs world{wo, wd, time};
+#ifdef RR_PHASE_STATS
+    Counts dummy = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Counts& pcnt = dummy;  // measurement build: the tests of the program's own ops are not counted
+#else
+    Counts& pcnt = cnt;
+#endif
     for (;;) {
         const Op op = next;
         const uint32_t this_pc = pc;
@@ -1011,19 +1017,51 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         const uint32_t code = uni(op.code) & 0xFFu;
         if (code == OP_END) break;
         if (code == OP_SUBTREE) {
+#ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
+            continue;
+#endif
             const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
             const bool enter = act && s.live;
             if (enter) s.m.begin(uni(op.ref), s.o, s.d, s.tmin, s.tmax, s.cur);
             const bool in = enter || rejoin;
             uint32_t steps = 0;
+#ifdef RR_PHASE_STATS
+            uint32_t pop_lanes = 0;
+#endif
             for (;;) {
                 const bool going = in && !s.m.finished();
                 const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
                 if (n == 0 || (n < park_below && steps >= min_steps)) break;
+#ifdef RR_PHASE_STATS  // measurement build: the six test counters carry (lanes, wave steps) of the node, leaf and return moves instead
+                if (COUNT) {
+                    const bool l0 = (threadIdx.x & 63u) == 0;
+                    const bool pn = going && trav_at_node(s.m);
+                    const bool an = __any(pn);
+                    cnt.box_tests += pn, cnt.sphere_tests += (l0 && an);
+                    if (going) trav_node<COUNT_OFF>(sc, s.m, stk, stride, cnt);
+                    const bool pl = going && trav_at_leaf(s.m);
+                    const bool al = __any(pl);
+                    cnt.inst_visits += pl, cnt.rect_tests += (l0 && al);
+                    if (going) trav_leaf<COUNT_OFF>(sc, s.m, world, stk, stride, cnt);
+                    const bool pp = going && s.m.node == NONE && s.m.sp != 0;
+                    const bool apop = __any(pp);
+                    cnt.tri_tests += (l0 && apop);
+                    cnt.samples += 0;
+                    cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += l0 ? 1u : 0u;
+                    if (pp) cnt.wave_steps += 0;
+                    pop_lanes += pp;
+                    if (going) trav_pop<COUNT_OFF>(sc, s.m, world, rng, stk, stride, cnt);
+                    steps += 1;
+                    continue;
+                }
+#endif
                 if (going) trav_step<COUNT>(sc, s.m, world, rng, stk, stride, cnt);
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
+#ifdef RR_PHASE_STATS
+            if (COUNT) cnt.samples += pop_lanes;  // (the samples counter carries the lanes of the return moves)
+#endif
             if (in) {
                 if (s.m.finished()) {
                     s.tmax = s.m.tmax;
@@ -1038,7 +1076,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             }
         } else if (act) {
             if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
-                if (COUNT && s.live) cnt.rect_tests++;
+                if (COUNT && s.live) pcnt.rect_tests++;
                 float t;
                 bool hit;
                 if (code == OP_RECT_XY)
@@ -1051,7 +1089,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 s.tmax = hit ? t : s.tmax;
                 s.cur = hit ? op.ref : s.cur;
             } else if (code == OP_CUBOID) {  // collider.rs:428-430: the six sides in the constructor's order (collider.rs:419-426)
-                if (COUNT && s.live) cnt.rect_tests += 6;
+                if (COUNT && s.live) pcnt.rect_tests += 6;
                 float t;
                 uint32_t side = NONE;
                 const bool live = s.live;
@@ -1066,10 +1104,10 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 s.o = wo;
                 s.d = wd;
             } else if (code == OP_TRANSLATE) {  // collider.rs:481
-                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) pcnt.inst_visits++;
                 s.o = s.o - mk3(op.f0, op.f1, op.f2);
             } else if (code >= OP_ROT_X && code <= OP_ROT_Z) {  // collider.rs:499-509
-                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
+                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) pcnt.inst_visits++;
                 const float sn = op.f0, c = op.f1;
                 const f3 o = s.o, d = s.d;
                 f3 no = o, nd = d;
@@ -1086,16 +1124,16 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 s.o = no;
                 s.d = nd;
             } else if (code == OP_SPHERE) {
-                if (COUNT && s.live) cnt.sphere_tests++;
+                if (COUNT && s.live) pcnt.sphere_tests++;
                 float t;
                 if (test_sphere(mk3(op.f0, op.f1, op.f2), op.f3, s.o, s.d, s.tmin, s.tmax, t) && s.live) {
                     s.tmax = t;
                     s.cur = op.ref;
                 }
             } else if (code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
-                if (s.live) eval_leaf<COUNT>(sc, uni(op.ref), s.o, s.d, time, s.tmin, s.tmax, s.cur, cnt);
+                if (s.live) eval_leaf<COUNT>(sc, uni(op.ref), s.o, s.d, time, s.tmin, s.tmax, s.cur, pcnt);
             } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
-                if (COUNT && s.live) cnt.inst_visits++;
+                if (COUNT && s.live) pcnt.inst_visits++;
                 s.m_tmin = s.tmin, s.m_tmax = s.tmax, s.m_cur = s.cur;
                 s.tmin = -kF32Max, s.tmax = kF32Max, s.cur = NONE;
             } else if (code == OP_MED_MID) {  // collider.rs:443: second probe over (t1 + 0.0001, f32::MAX)
