@@ -473,6 +473,74 @@ struct Trav {
 __device__ __forceinline__ bool trav_at_node(const Trav& m) { return m.node != NONE && dtag(m.node) == RR_TAG_BVH; }
 __device__ __forceinline__ bool trav_at_leaf(const Trav& m) { return m.node != NONE && dtag(m.node) != RR_TAG_BVH; }
 
+// The box test of a BVH node of class `cls` (not BVH_CLASS_NO_BOX) for the ray and range of m: the reference's test, and in
+// the culling classes the three-sided test on the grown box as well.
+__device__ __forceinline__ bool node_box_pass(const DevScene& sc, const Trav& m, f3 bmin, f3 bmax, uint32_t cls) {
+    // Slab parameters of the three axes, entry and exit ordered by the sign of 1/direction.
+    const float tx0 = (bmin.x - m.o.x) * m.inv.x, tx1 = (bmax.x - m.o.x) * m.inv.x;
+    const float ty0 = (bmin.y - m.o.y) * m.inv.y, ty1 = (bmax.y - m.o.y) * m.inv.y;
+    const float tz0 = (bmin.z - m.o.z) * m.inv.z, tz1 = (bmax.z - m.o.z) * m.inv.z;
+    const bool nx = m.inv.x < 0.0f, ny = m.inv.y < 0.0f, nz = m.inv.z < 0.0f;
+    const float ex = nx ? tx1 : tx0, fx = nx ? tx0 : tx1;
+    const float ey = ny ? ty1 : ty0, fy = ny ? ty0 : ty1;
+    const float ez = nz ? tz1 : tz0, fz = nz ? tz0 : tz1;
+    // aabb.rs:37-52: only axes with a negative 1/direction clip [t_min, t_max], by
+    // `t1 > t_min ? t1 : t_min` and `t0 < t_max ? t0 : t_max` (a NaN never replaces a bound:
+    // fmaxf/fminf keep the other operand too), and the node is rejected once t_max <= t_min.
+    // Bounds only tighten, so testing once after the third axis rejects the same rays.
+    const float lo = fmaxf(fmaxf(m.tmin, nx ? ex : m.tmin), fmaxf(ny ? ey : m.tmin, nz ? ez : m.tmin));
+    const float hi = fminf(fminf(m.tmax, nx ? fx : m.tmax), fminf(ny ? fy : m.tmax, nz ? fz : m.tmax));
+    // (A bound that is NaN on entry — the t of a degenerate hit — stays NaN in the reference and
+    // fails no comparison, where fmaxf/fminf would drop it.)
+    bool pass = !(hi <= lo) || __builtin_isunordered(m.tmin, m.tmax);
+    if (cls >= BVH_CLASS_CULL_RANGE && m.cull) {
+        // All three slabs of the box grown by the margin, against the segment no accepted hit can lie
+        // outside of.  The margin grows with the squared distance from the ray origin to the farthest
+        // point of the box, as the rounding errors of the intersectors below do.
+        const float ax = fmaxf(fabsf(bmin.x - m.o.x), fabsf(bmax.x - m.o.x)), ay = fmaxf(fabsf(bmin.y - m.o.y), fabsf(bmax.y - m.o.y)),
+                    az = fmaxf(fabsf(bmin.z - m.o.z), fabsf(bmax.z - m.o.z));
+        const float g = sc.cull_eps + sc.cull_k * (ax * ax + ay * ay + az * az);
+        const float gx = g * fabsf(m.inv.x), gy = g * fabsf(m.inv.y), gz = g * fabsf(m.inv.z);
+        const float seg0 = cls == BVH_CLASS_CULL_ANY_T ? 0.0f : m.tmin, seg1 = cls == BVH_CLASS_CULL_ANY_T ? kF32Max : m.tmax;
+        const float enter = fmaxf(fmaxf(seg0, ex - gx), fmaxf(ey - gy, ez - gz));
+        const float leave = fminf(fminf(seg1, fx + gx), fminf(fy + gy, fz + gz));
+        pass = pass && !(leave < enter);
+    }
+    return pass;
+}
+
+// What follows a passed box test (collider.rs:546-580): the first child by the sign of direction[axis], and the frame that
+// names what comes after it.  `left` and `right` are the node's words (child ref, and axis or class in the spare bits).
+__device__ __forceinline__ void node_descend(Trav& m, uint32_t idx, uint32_t left, uint32_t right, uint32_t cls, uint32_t* stk, uint32_t stride) {
+    const uint32_t l = left & REF_MASK, r = right & REF_MASK;
+    const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
+    // In the culling classes evaluating the same child twice over the same or a smaller
+    // range cannot change the outcome.  The reference-order counting build evaluates everything.
+    const bool pure = cls >= BVH_CLASS_CULL_RANGE;
+    if (pure && l == r) {
+        m.node = l;  // span-1 node: the second visit repeats the first
+    } else {
+        uint32_t fw;
+        if (!dirpos)
+            fw = l;  // right first; left follows after a hit and after a miss alike
+        else if (pure)
+            fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
+        else
+            fw = frame_word(FK_BVH2, idx);
+        stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
+        m.sp += 1;
+        m.hitf = false;
+        m.node = dirpos ? l : r;
+    }
+}
+
+// The class a build of the kernels treats a node of stored class `stored` as: the reference-order counting build makes every
+// visit the reference makes.
+template <int COUNT>
+__device__ __forceinline__ uint32_t node_class(uint32_t stored) {
+    return COUNT == COUNT_REFERENCE ? (stored != BVH_CLASS_NO_BOX ? BVH_CLASS_REFERENCE : BVH_CLASS_NO_BOX) : stored;
+}
+
 template <int COUNT>
 __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ BVH node
@@ -481,62 +549,79 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
         const float4 q0 = sc.bvh[2 * idx], q1 = sc.bvh[2 * idx + 1];
         m.node = NONE;
         const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
-        const uint32_t cls = COUNT == COUNT_REFERENCE ? (dextra(right) != BVH_CLASS_NO_BOX ? BVH_CLASS_REFERENCE : BVH_CLASS_NO_BOX) : dextra(right);
+        const uint32_t cls = node_class<COUNT>(dextra(right));
         bool pass = true;
         if (cls != BVH_CLASS_NO_BOX) {
             if (COUNT) cnt.box_tests++;
-            // Slab parameters of the three axes, entry and exit ordered by the sign of 1/direction.
-            const float tx0 = (q0.x - m.o.x) * m.inv.x, tx1 = (q1.x - m.o.x) * m.inv.x;
-            const float ty0 = (q0.y - m.o.y) * m.inv.y, ty1 = (q1.y - m.o.y) * m.inv.y;
-            const float tz0 = (q0.z - m.o.z) * m.inv.z, tz1 = (q1.z - m.o.z) * m.inv.z;
-            const bool nx = m.inv.x < 0.0f, ny = m.inv.y < 0.0f, nz = m.inv.z < 0.0f;
-            const float ex = nx ? tx1 : tx0, fx = nx ? tx0 : tx1;
-            const float ey = ny ? ty1 : ty0, fy = ny ? ty0 : ty1;
-            const float ez = nz ? tz1 : tz0, fz = nz ? tz0 : tz1;
-            // aabb.rs:37-52: only axes with a negative 1/direction clip [t_min, t_max], by
-            // `t1 > t_min ? t1 : t_min` and `t0 < t_max ? t0 : t_max` (a NaN never replaces a bound:
-            // fmaxf/fminf keep the other operand too), and the node is rejected once t_max <= t_min.
-            // Bounds only tighten, so testing once after the third axis rejects the same rays.
-            const float lo = fmaxf(fmaxf(m.tmin, nx ? ex : m.tmin), fmaxf(ny ? ey : m.tmin, nz ? ez : m.tmin));
-            const float hi = fminf(fminf(m.tmax, nx ? fx : m.tmax), fminf(ny ? fy : m.tmax, nz ? fz : m.tmax));
-            // (A bound that is NaN on entry — the t of a degenerate hit — stays NaN in the reference and
-            // fails no comparison, where fmaxf/fminf would drop it.)
-            pass = !(hi <= lo) || __builtin_isunordered(m.tmin, m.tmax);
-            if (cls >= BVH_CLASS_CULL_RANGE && m.cull) {
-                // All three slabs of the box grown by the margin, against the segment no accepted hit can lie
-                // outside of.  The margin grows with the squared distance from the ray origin to the farthest
-                // point of the box, as the rounding errors of the intersectors below do.
-                const float ax = fmaxf(fabsf(q0.x - m.o.x), fabsf(q1.x - m.o.x)), ay = fmaxf(fabsf(q0.y - m.o.y), fabsf(q1.y - m.o.y)),
-                            az = fmaxf(fabsf(q0.z - m.o.z), fabsf(q1.z - m.o.z));
-                const float g = sc.cull_eps + sc.cull_k * (ax * ax + ay * ay + az * az);
-                const float gx = g * fabsf(m.inv.x), gy = g * fabsf(m.inv.y), gz = g * fabsf(m.inv.z);
-                const float seg0 = cls == BVH_CLASS_CULL_ANY_T ? 0.0f : m.tmin, seg1 = cls == BVH_CLASS_CULL_ANY_T ? kF32Max : m.tmax;
-                const float enter = fmaxf(fmaxf(seg0, ex - gx), fmaxf(ey - gy, ez - gz));
-                const float leave = fminf(fminf(seg1, fx + gx), fminf(fy + gy, fz + gz));
-                pass = pass && !(leave < enter);
+            pass = node_box_pass(sc, m, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), cls);
+        }
+        if (pass) node_descend(m, idx, left, right, cls, stk, stride);
+    }
+}
+
+// The leaf and return moves for subtrees that hold nothing but BVH nodes over spheres, rects, triangles and cuboids ("simple"
+// subtrees): no lists, instances, media or moving spheres below, so neither the world ray, the ray's time nor random numbers
+// are needed, and every frame on the stack is a BVH node's.
+template <int COUNT>
+__device__ __forceinline__ void trav_leaf_simple(const DevScene& sc, Trav& m, Counts& cnt) {
+    if (m.node != NONE && dtag(m.node) != RR_TAG_BVH) {
+        const uint32_t node = m.node;
+        const uint32_t tag = dtag(node), idx = didx(node);
+        const float4* rp = sc.tri;  // one address, three 16-byte loads and one wait, whatever the record
+        uint32_t roff = 3 * idx;
+        if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
+        if (tag == RR_TAG_RECT) rp = sc.rect, roff = 2 * idx;
+        if (tag == RR_TAG_CUBOID) rp = sc.cuboid, roff = 2 * idx;
+        const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
+        m.node = NONE;
+        if (tag == RR_TAG_SPHERE) {
+            if (COUNT) cnt.sphere_tests++;
+            float t;
+            if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, m.cur = node, m.hitf = true;
+        } else if (tag == RR_TAG_TRIANGLE) {
+            if (COUNT) cnt.tri_tests++;
+            float t;
+            if (test_triangle(q0, q1, q2, m.o, m.d, t)) m.tmax = t, m.cur = node, m.hitf = true;
+        } else if (tag == RR_TAG_RECT) {
+            if (COUNT) cnt.rect_tests++;
+            float t, ca, cb;
+            if (test_rect(q0, q1.x, __float_as_uint(q1.y), m.o, m.d, m.tmin, m.tmax, t, ca, cb)) m.tmax = t, m.cur = node, m.hitf = true;
+        } else {  // RR_TAG_CUBOID: six rects as a linear closest-hit list (collider.rs:428-430 -> 751-772)
+            const uint32_t first = __float_as_uint(q0.w);
+            if (COUNT) cnt.rect_tests += 6;
+            if (__float_as_uint(q1.w) != 0u) {  // the sides are the constructor's (collider.rs:86-101): all six follow from the corners
+                float t;
+                uint32_t side = NONE;
+                if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q1.z, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 0;
+                if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q0.z, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 1;
+                if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q1.y, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 2;
+                if (test_rect_axis<RR_RECT_XZ>(q0.x, q1.x, q0.z, q1.z, q0.y, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 3;
+                if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q1.x, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 4;
+                if (test_rect_axis<RR_RECT_YZ>(q0.y, q1.y, q0.z, q1.z, q0.x, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 5;
+                if (side != NONE) m.cur = dref(RR_TAG_RECT, first + side), m.hitf = true;
+            } else {
+                for (uint32_t i = 0; i < 6; ++i) {
+                    const float4 r0 = sc.rect[2 * (first + i)], r1 = sc.rect[2 * (first + i) + 1];
+                    float t, ca, cb;
+                    if (test_rect(r0, r1.x, __float_as_uint(r1.y), m.o, m.d, m.tmin, m.tmax, t, ca, cb))
+                        m.tmax = t, m.cur = dref(RR_TAG_RECT, first + i), m.hitf = true;
+                }
             }
         }
-        if (pass) {
-            const uint32_t l = left & REF_MASK, r = right & REF_MASK;
-            const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
-            // In the culling classes evaluating the same child twice over the same or a smaller
-            // range cannot change the outcome.  The reference-order counting build evaluates everything.
-            const bool pure = cls >= BVH_CLASS_CULL_RANGE;
-            if (pure && l == r) {
-                m.node = l;  // span-1 node: the second visit repeats the first
-            } else {
-                uint32_t fw;
-                if (!dirpos)
-                    fw = l;  // right first; left follows after a hit and after a miss alike
-                else if (pure)
-                    fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
-                else
-                    fw = frame_word(FK_BVH2, idx);
-                stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
-                m.sp += 1;
-                m.hitf = false;
-                m.node = dirpos ? l : r;
-            }
+    }
+}
+
+__device__ __forceinline__ void trav_pop_simple(const DevScene& sc, Trav& m, uint32_t* stk, uint32_t stride) {
+    if (m.node == NONE && m.sp != 0) {  // one return per move, as in trav_pop
+        const uint32_t fw = stk[(m.sp - 1) * stride];
+        m.sp -= 1;
+        const bool first_hit = m.hitf;
+        m.hitf = first_hit || (fw & FW_FLAG);
+        if (dtag(fw) == FK_BVH2) {  // left went first: right with t_max = the hit's t, or left once more after a miss
+            const uint32_t idx = didx(fw);
+            m.node = __float_as_uint(first_hit ? sc.bvh[2 * idx + 1].w : sc.bvh[2 * idx].w) & REF_MASK;
+        } else {  // collider.rs:546-580 after the first child came back: the frame names what comes next
+            m.node = (!first_hit && (fw & FW_MISS_NONE)) ? NONE : (fw & REF_MASK);
         }
     }
 }
@@ -837,7 +922,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
 // w2..w7 = six f32 operands.
 constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
                    OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
-                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15;
+                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16;
 constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
 
 struct Op {
@@ -925,7 +1010,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
             }
         } else if (VEC && code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
             if (live) eval_leaf<COUNT>(sc, uni(op.ref), o, d, time, tmin, tmax, cur, cnt);
-        } else if (VEC && code == OP_SUBTREE) {  // BVH (or any shape the program does not flatten): per-lane machine
+        } else if (VEC && (code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE)) {  // BVH (or any shape the program does not flatten): per-lane machine
 #ifndef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             if (live) machine<COUNT>(sc, uni(op.ref), wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
 #endif
@@ -965,10 +1050,14 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
 // The same interpreter for a kernel whose lanes may leave a BVH subtree unfinished and come back to it in
 // a later call ("parking").  A wave waits in OP_SUBTREE for the deepest descent among its lanes; when only
 // a few lanes are still descending, waiting wastes the others.  Here those few keep their traversal state
-// (machine registers, LDS stack, the interpreter state below) and sit out the rest of the call; in the next
+// (machine state, LDS stack, the interpreter state below) and sit out the rest of the call; in the next
 // call of the wave they skip the ops before the subtree they are parked at, join the lanes that enter it
 // then, and go on with the rest of the program once their descent is complete.  Every lane still executes
 // its own ops in program order on its own state, so the result is the one traverse() computes.
+//
+// Between calls a parked lane's state lives in LDS, in one of a few slots per wave, not in registers: only
+// a handful of lanes are parked at a time, and thirty registers held for them by every lane of the kernel
+// (through shading, where the kernel needs most) were what made it spill.
 struct ProgState {
     f3 o, d;  // the ray in the space the program is in
     float tmin, tmax;
@@ -976,7 +1065,6 @@ struct ProgState {
     bool live;
     float m_tmin, m_tmax, m_t1;  // the enclosing call's range and probe 1 of the open medium
     uint32_t m_cur;
-    Trav m;
     uint32_t park_pc;  // the OP_SUBTREE this lane is parked at
     bool parked;
     __device__ __forceinline__ void start(f3 wo, f3 wd, float tmin_, float tmax_) {
@@ -991,24 +1079,104 @@ struct ProgState {
     }
 };
 
-// `enabled`: the lane has a ray, started with ProgState::start() before this call or parked by an earlier one.
+constexpr uint32_t PARK_SLOTS = 24;  // parked lanes a wave can hold
+constexpr uint32_t PARK_WORDS = 22;  // machine: o, d, tmin, tmax, cur, node, sp and flags; program: o, d, tmin, the open medium's four
+constexpr uint32_t PARK_LDS_WORDS_PER_WAVE = PARK_SLOTS * PARK_WORDS;
+constexpr uint32_t PARK_PC_MASK = 0xFFFFFFu;
+struct ParkArea {        // wave-uniform
+    uint32_t* slots;     // word w of slot k at slots[w * PARK_SLOTS + k]
+    uint32_t free_mask;  // bit k: slot k is free
+    __device__ __forceinline__ void init(uint32_t* lds_after_stacks) {
+        slots = lds_after_stacks + (threadIdx.x >> 6) * PARK_LDS_WORDS_PER_WAVE;
+        free_mask = (1u << PARK_SLOTS) - 1u;
+    }
+};
+__device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, const ProgState& s, const Trav& m) {
+    uint32_t* w = pa.slots + slot;
+    const float v[18] = {m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, m.tmin, m.tmax, s.o.x, s.o.y, s.o.z, s.d.x, s.d.y, s.d.z, s.tmin, s.m_tmin, s.m_tmax, s.m_t1};
+#pragma unroll
+    for (uint32_t k = 0; k < 18; ++k) w[k * PARK_SLOTS] = __float_as_uint(v[k]);
+    w[18 * PARK_SLOTS] = m.cur;
+    w[19 * PARK_SLOTS] = m.node;
+    w[20 * PARK_SLOTS] = m.sp | (m.hitf ? 1u << 31 : 0u) | (s.live ? 1u << 30 : 0u);
+    w[21 * PARK_SLOTS] = s.m_cur;
+}
+__device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, ProgState& s, Trav& m) {
+    const uint32_t* w = pa.slots + slot;
+    float v[18];
+#pragma unroll
+    for (uint32_t k = 0; k < 18; ++k) v[k] = __uint_as_float(w[k * PARK_SLOTS]);
+    m.set_ray(mk3(v[0], v[1], v[2]), mk3(v[3], v[4], v[5]));  // (1/direction and the culling flag follow from the ray)
+    m.tmin = v[6], m.tmax = v[7];
+    s.o = mk3(v[8], v[9], v[10]), s.d = mk3(v[11], v[12], v[13]);
+    s.tmin = v[14], s.m_tmin = v[15], s.m_tmax = v[16], s.m_t1 = v[17];
+    m.cur = w[18 * PARK_SLOTS];
+    m.node = w[19 * PARK_SLOTS];
+    const uint32_t f = w[20 * PARK_SLOTS];
+    m.sp = f & 0xFFFFu, m.hitf = (f >> 31) != 0u, s.live = ((f >> 30) & 1u) != 0u;
+    s.m_cur = w[21 * PARK_SLOTS];
+}
+
+// After a visit of a subtree: lanes whose descent is complete take its result and give their slot back; the others
+// are parked at `this_pc`, in the slot they have or in a free one.  Wave-uniform control flow.
+__device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Trav& m, uint32_t& slot, bool in, uint32_t this_pc, bool& act) {
+    const bool done = in && m.finished();
+    uint64_t fm = __ballot(done && s.parked);  // slots coming back
+    while (fm != 0) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(fm));
+        fm &= fm - 1;
+        pa.free_mask |= 1u << __builtin_amdgcn_readlane(slot, l);
+    }
+    uint64_t nm = __ballot(in && !done && !s.parked);  // lanes parked for the first time
+    while (nm != 0) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(nm));
+        nm &= nm - 1;
+        const uint32_t k = static_cast<uint32_t>(__builtin_ctz(pa.free_mask));  // (the visit did not end with more such lanes than free slots)
+        pa.free_mask &= ~(1u << k);
+        if ((threadIdx.x & 63u) == l) slot = k;
+    }
+    if (in) {
+        if (done) {
+            s.tmax = m.tmax;
+            s.cur = m.cur;
+            s.parked = false;
+            act = true;
+        } else {
+            s.parked = true;
+            s.park_pc = this_pc;
+            act = false;
+            park_save(pa, slot, s, m);
+        }
+    }
+}
+
+// `enabled`: the lane has a ray: a new one (park == NONE: the program starts for it with the range [tmin0, tmax0]) or one
+// parked by an earlier call (`park` names its slot and the op it is parked at).
 // `park_below`: lanes still descending are parked once fewer than this many are left (0: never park), but not
 // before `min_steps` machine steps have been taken in this visit, so that parked lanes always make progress.
-// On return a lane with s.parked set has no result yet; the others have theirs in (s.tmax, s.cur).
+// On return a lane with park != NONE has no result yet; the others have theirs in (t_hit, ref_hit).
 template <int COUNT>
-__device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, bool enabled, ProgState& s, Rng& rng,
-                                                 uint32_t* stk, uint32_t stride, uint32_t park_below, uint32_t min_steps, Counts& cnt) {
+__device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, float tmin0, float tmax0, bool enabled,
+                                                 uint32_t& park, ParkArea& pa, Rng& rng, uint32_t* stk, uint32_t stride, uint32_t park_below,
+                                                 uint32_t min_steps, Counts& cnt, float& t_hit, uint32_t& ref_hit) {
+    ProgState s;
+    s.start(wo, wd, tmin0, tmax0);
+    uint32_t slot = park >> 24;
+    if (enabled && park != NONE) {  // (its state is fetched from its slot when the program comes to the op it is parked at)
+        s.parked = true;
+        s.park_pc = park & PARK_PC_MASK;
+    }
     bool act = enabled && !s.parked;  // the lane executes the ops it comes to
     const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
     Op next = prog[0];
     uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
     const WorldInRegs world{wo, wd, time};
-#ifdef RR_PHASE_STATS
-    Counts dummy = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    Counts& pcnt = dummy;  // measurement build: the tests of the program's own ops are not counted
-#else
     Counts& pcnt = cnt;
-#endif
+    // a visit may end with lanes still descending only while there are slots for the ones that have none yet
+    auto may_park = [&](bool going, uint32_t n, uint32_t steps) {
+        if (!(n < park_below && steps >= min_steps)) return false;
+        return static_cast<uint32_t>(__popcll(__ballot(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
+    };
     for (;;) {
         const Op op = next;
         const uint32_t this_pc = pc;
@@ -1016,64 +1184,63 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         next = prog[pc];
         const uint32_t code = uni(op.code) & 0xFFu;
         if (code == OP_END) break;
-        if (code == OP_SUBTREE) {
+        if (code == OP_SUBTREE_SIMPLE) {
+#ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
+            continue;
+#endif
+            // A subtree of BVH nodes over spheres, rects, triangles and cuboids.  The root's box and class travel in the op:
+            // its test (collider.rs:537-545) is made here for all lanes at once, with scalar operands, and only the lanes
+            // that pass descend, on the moves that know nothing but BVH frames and those four kinds of leaves.
+            const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
+            Trav m;
+            m.begin(NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
+            if (rejoin) park_load(pa, slot, s, m);
+            const uint32_t root = uni(op.ref), ridx = didx(root);
+            const uint32_t cls = node_class<COUNT>((uni(op.code) >> 8) & 3u);  // the root has a box (or the op would not be this one)
+            bool enter = false;
+            if (act && s.live) {
+                if (COUNT) cnt.box_tests++;
+                enter = node_box_pass(sc, m, mk3(op.f0, op.f1, op.f2), mk3(op.f3, op.f4, op.f5), cls);
+            }
+            if (__any(enter)) {
+                const uint32_t left = __float_as_uint(sc.bvh[2 * ridx].w), right = __float_as_uint(sc.bvh[2 * ridx + 1].w);
+                if (enter) node_descend(m, ridx, left, right, cls, stk, stride);
+            }
+            const bool in = enter || rejoin;
+            uint32_t steps = 0;
+            for (;;) {
+                const bool going = in && !m.finished();
+                const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
+                if (n == 0 || may_park(going, n, steps)) break;
+                if (going) {
+                    trav_node<COUNT>(sc, m, stk, stride, cnt);
+                    trav_leaf_simple<COUNT>(sc, m, cnt);
+                    trav_pop_simple(sc, m, stk, stride);
+                }
+                if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
+                steps += 1;
+            }
+            park_settle(pa, s, m, slot, in, this_pc, act);
+        } else if (code == OP_SUBTREE) {
 #ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             continue;
 #endif
             const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
             const bool enter = act && s.live;
-            if (enter) s.m.begin(uni(op.ref), s.o, s.d, s.tmin, s.tmax, s.cur);
+            Trav m;
+            m.begin(enter ? uni(op.ref) : NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
+            if (rejoin) park_load(pa, slot, s, m);
             const bool in = enter || rejoin;
             uint32_t steps = 0;
-#ifdef RR_PHASE_STATS
-            uint32_t pop_lanes = 0;
-#endif
             for (;;) {
-                const bool going = in && !s.m.finished();
+                const bool going = in && !m.finished();
                 const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
-                if (n == 0 || (n < park_below && steps >= min_steps)) break;
-#ifdef RR_PHASE_STATS  // measurement build: the six test counters carry (lanes, wave steps) of the node, leaf and return moves instead
-                if (COUNT) {
-                    const bool l0 = (threadIdx.x & 63u) == 0;
-                    const bool pn = going && trav_at_node(s.m);
-                    const bool an = __any(pn);
-                    cnt.box_tests += pn, cnt.sphere_tests += (l0 && an);
-                    if (going) trav_node<COUNT_OFF>(sc, s.m, stk, stride, cnt);
-                    const bool pl = going && trav_at_leaf(s.m);
-                    const bool al = __any(pl);
-                    cnt.inst_visits += pl, cnt.rect_tests += (l0 && al);
-                    if (going) trav_leaf<COUNT_OFF>(sc, s.m, world, stk, stride, cnt);
-                    const bool pp = going && s.m.node == NONE && s.m.sp != 0;
-                    const bool apop = __any(pp);
-                    cnt.tri_tests += (l0 && apop);
-                    cnt.samples += 0;
-                    cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += l0 ? 1u : 0u;
-                    if (pp) cnt.wave_steps += 0;
-                    pop_lanes += pp;
-                    if (going) trav_pop<COUNT_OFF>(sc, s.m, world, rng, stk, stride, cnt);
-                    steps += 1;
-                    continue;
-                }
-#endif
-                if (going) trav_step<COUNT>(sc, s.m, world, rng, stk, stride, cnt);
+                if (n == 0 || may_park(going, n, steps)) break;
+                if (going) trav_step<COUNT>(sc, m, world, rng, stk, stride, cnt);
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
-#ifdef RR_PHASE_STATS
-            if (COUNT) cnt.samples += pop_lanes;  // (the samples counter carries the lanes of the return moves)
-#endif
-            if (in) {
-                if (s.m.finished()) {
-                    s.tmax = s.m.tmax;
-                    s.cur = s.m.cur;
-                    s.parked = false;
-                    act = true;
-                } else {
-                    s.parked = true;
-                    s.park_pc = this_pc;
-                    act = false;
-                }
-            }
+            park_settle(pa, s, m, slot, in, this_pc, act);
         } else if (act) {
             if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
                 if (COUNT && s.live) pcnt.rect_tests++;
@@ -1162,6 +1329,9 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             }
         }
     }
+    park = s.parked ? ((slot << 24) | s.park_pc) : NONE;
+    t_hit = s.tmax;
+    ref_hit = s.cur;
 }
 
 // ---------------------------------------------------------- hit records
@@ -1350,7 +1520,14 @@ __device__ __forceinline__ uint32_t f32_as_u32_sat(float f) {  // Rust `as u32`
     return static_cast<uint32_t>(f);
 }
 
-__device__ __forceinline__ f3 texture_color(const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
+// Out of line on purpose: materials of one solid colour never come here (DevMaterial::solid), and inlined into the kernels the
+// turbulence loop costs every path the registers it needs (measured: 50 fewer spilled registers, +3 % on the BVH scenes).
+#ifdef RR_INLINE_TEX
+__device__ __forceinline__ f3 texture_color(
+#else
+__device__ __attribute__((noinline)) f3 texture_color(
+#endif
+    const DevScene& sc, uint32_t tex, float u, float v, f3 p) {  // texture.rs:66-103
 #ifdef RR_ABLATE_TEXTURES
     return mk3(u, v, p.x);
 #endif

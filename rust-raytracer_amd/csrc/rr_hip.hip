@@ -324,6 +324,7 @@ struct Below {
     bool bounded = true;   // false: something below has no finite bounds
     bool has_tri = false;  // triangles accept hits outside the caller's t range (collider.rs:627)
     bool has_medium = false;
+    bool simple = true;    // nothing but BVH nodes over spheres, rects, triangles and cuboids
     void add_point(double x, double y, double z) {
         const double p[3] = {x, y, z};
         for (int a = 0; a < 3; ++a) {
@@ -340,6 +341,7 @@ struct Below {
         bounded &= o.bounded;
         has_tri |= o.has_tri;
         has_medium |= o.has_medium;
+        simple &= o.simple;
     }
     bool empty() const { return lo[0] > hi[0]; }
 };
@@ -407,6 +409,7 @@ struct Walker {
                 // free to choose: a BVH node over a moving sphere has no bounds to cull with
                 below.add_point(p.center0[0], p.center0[1], p.center0[2]);
                 below.bounded = false;
+                below.simple = false;
                 return mat_ok(p.material);
             }
             case RR_TAG_RECT: {
@@ -478,6 +481,7 @@ struct Walker {
                 uint32_t w;
                 if (!walk(s.media[idx].boundary, owner, level + 1, w, below)) return false;
                 below.has_medium = true;
+                below.simple = false;
                 words = FRAME_WORDS_MEDIUM + w;
                 return true;
             }
@@ -496,6 +500,7 @@ struct Walker {
                 words = FRAME_WORDS_INST + w;
                 // bounds of the child's box seen from outside the instance (collider.rs:484, 513-517)
                 below = inner;
+                below.simple = false;
                 if (!inner.empty()) {
                     for (int a = 0; a < 3; ++a) below.lo[a] = 1e300, below.hi[a] = -1e300;
                     for (int c = 0; c < 8; ++c) {
@@ -543,6 +548,7 @@ struct Walker {
                     wmax = std::max(wmax, w);
                 }
                 words = FRAME_WORDS_LIST + wmax;
+                below.simple = false;
                 return true;
             }
         }
@@ -575,6 +581,8 @@ bool cuboid_corners(const rr_flat_scene& s, uint32_t ci, float p0[3], float p1[3
 // one OP_SUBTREE for the per-lane machine.
 struct ProgramBuilder {
     const rr_flat_scene& s;
+    const std::vector<Below>& bvh_below;     // per BVH node: what lies below it
+    const std::vector<uint8_t>& bvh_class;   // per BVH node: BVH_CLASS_*
     std::vector<Op> ops;
     std::vector<uint32_t> chain;  // instances enclosing the node being emitted, outermost first
     std::vector<uint32_t> space;  // instances the ops emitted so far have applied to the ray
@@ -665,10 +673,16 @@ struct ProgramBuilder {
                 ops.push_back(make(OP_MED_END, dref(tag, idx), s.media[idx].neg_inv_density));
                 in_medium = false;
                 break;
-            default:  // RR_TAG_BVH
+            default: {  // RR_TAG_BVH
                 ensure_space();
-                ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
+                const rr_bvh_node& n = s.bvh_nodes[idx];
+                if (bvh_below[idx].simple && n.has_box)  // the root's box and class travel in the op: its test is made before the descent is handed out
+                    ops.push_back(make(OP_SUBTREE_SIMPLE | (static_cast<uint32_t>(bvh_class[idx]) << 8), dref(tag, idx), n.bmin[0], n.bmin[1], n.bmin[2],
+                                       n.bmax[0], n.bmax[1], n.bmax[2]));
+                else
+                    ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
                 break;
+            }
         }
     }
 };
@@ -796,8 +810,9 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     int grid_full = 0;
     if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_traverse), &grid_full)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
+    const size_t lds_finish = lds + 4u * PARK_LDS_WORDS_PER_WAVE * 4u;  // the stacks, then each wave's slots for parked lanes
     int grid_finish = 0;
-    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_finish), &grid_finish)) return rc;
+    if (int rc = launch_dims(ctx, lds_finish, reinterpret_cast<const void*>(k_finish), &grid_finish)) return rc;
     hipStream_t aux = ctx->wf_aux;
 
     // A batch takes its camera rays as one pair of launches over the queue of all its paths, then one launch of
@@ -867,7 +882,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
             // (a wave that finds the queue empty leaves at once)
             const uint32_t grid_f = std::min<uint32_t>((finish_bound + 256u * RR_WF_FINISH_PATHS_PER_LANE - 1u) / (256u * RR_WF_FINISH_PATHS_PER_LANE),
                                                        static_cast<uint32_t>(grid_finish));
-            hipLaunchKernelGGL(k_finish, dim3(grid_f), dim3(256), lds, aux, ctx->sc, a, st, finish_queue, finish_ctl, counters);
+            hipLaunchKernelGGL(k_finish, dim3(grid_f), dim3(256), lds_finish, aux, ctx->sc, a, st, finish_queue, finish_ctl, counters);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, aux, a, st, sums);
@@ -886,8 +901,8 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
 // The persistent renderer at path granularity: batches of samples of every slot, each one launch of k_wf_paths that
 // leaves every sample's value in `values` (room for `capacity` paths), and the in-order accumulation of the batch.
 // Allocates nothing: the caller brings the values' memory and the device word the waves claim their paths from.
-int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned long long* counters, hipStream_t stream, float4* values,
-                    uint64_t capacity, unsigned int* next_path) {
+int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned long long* counters, hipStream_t stream,
+                    float4* values, uint64_t capacity, unsigned int* next_path) {
     const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, capacity / a.n_slots);
     if (most == 0) return fail(RR_E_LIMIT, "render_paths: the sample values of one sample per (slice, pixel) do not fit the workspace");
     const uint64_t batch = std::min<uint64_t>(most, std::max(a.spt, 1u));
@@ -900,7 +915,8 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
                              : count == COUNT_REFERENCE ? k_wf_paths<COUNT_REFERENCE, true, true> : k_wf_paths<COUNT_OFF, true, true>)
         : ctx->prog_vector_ops ? (count ? k_wf_paths<COUNT_REFERENCE, true> : k_wf_paths<COUNT_OFF, true>)
                                : (count ? k_wf_paths<COUNT_REFERENCE, false> : k_wf_paths<COUNT_OFF, false>);
-    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+    // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + (ctx->has_subtrees ? 4u * PARK_LDS_WORDS_PER_WAVE * 4u : 0u);
     int grid = 0;
     if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
@@ -1085,6 +1101,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     constexpr size_t PAD = 3;
     std::vector<float4> bvh(static_cast<size_t>(s->n_bvh_nodes) * 2 + PAD);
     uint32_t class_count[4] = {0, 0, 0, 0};
+    std::vector<uint8_t> bvh_class(s->n_bvh_nodes, 0);
     for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
         const rr_bvh_node& n = s->bvh_nodes[i];
         bvh[2 * i] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], u2f(to_dref(n.left, n.axis)));
@@ -1102,6 +1119,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
             if (holds) cls = b.has_tri ? BVH_CLASS_CULL_ANY_T : BVH_CLASS_CULL_RANGE;
         }
         bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, cls)));
+        bvh_class[i] = static_cast<uint8_t>(cls);
         if (wk.seen[RR_TAG_BVH][i]) class_count[cls]++;
     }
     std::vector<float4> sphere(s->n_spheres + PAD);
@@ -1212,7 +1230,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevImage> images(s->n_images);
     for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
-    ProgramBuilder pb{*s, {}, {}, {}, false};
+    ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false};
     pb.emit(s->root);
     pb.ops.push_back(ProgramBuilder::make(OP_END));
     pb.ops.push_back(ProgramBuilder::make(OP_END));  // the interpreter prefetches one op past the one it runs
@@ -1267,9 +1285,10 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     uint32_t top_ops = 0;  // ops of the scene program that test or transform something outside the BVH subtrees
     for (const Op& op : pb.ops) {
         const uint32_t code = op.code & 0xFFu;
-        ctx->has_subtrees |= code == OP_SUBTREE;
-        ctx->prog_vector_ops |= code == OP_SUBTREE || code == OP_LEAF_REF;
-        top_ops += code != OP_SUBTREE && code != OP_END && code != OP_RESET;
+        const bool subtree = code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE;
+        ctx->has_subtrees |= subtree;
+        ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
+        top_ops += !subtree && code != OP_END && code != OP_RESET;
     }
     // Scenes with BVH subtrees: when nearly everything is inside the subtrees, the bounce kernels of the wavefront
     // pipeline (pure traversal at twice the occupancy) are the faster way through the camera rays; when the scene
@@ -1394,6 +1413,7 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
         w.height = p->height;
         w.n_pixels = static_cast<uint32_t>(n_pixels);
         w.pixel0 = row0 * p->width;
+        w.stack_words = ctx->info.stack_words;
         w.spt = spt;
         w.max_depth = p->max_depth;
         w.sample_offset = p->sample_offset;

@@ -65,6 +65,7 @@ struct WfArgs {
     uint32_t slice_out;    // index of that slice inside the output buffer
     uint32_t max_depth;
     uint32_t sample_offset;
+    uint32_t stack_words;  // words of traversal stack per lane: the wave's slots for parked lanes follow the stacks in LDS
     uint64_t seed;
 };
 
@@ -151,12 +152,10 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
     float time = 0.f;
     // PARK (scenes with BVH subtrees): the few lanes with the deepest descents do not hold the wave in a subtree;
     // they keep their traversal state and come back to it in later turns (traverse_parking)
-    ProgState ps;
+    ParkArea pa;
+    uint32_t park = NONE;  // the slot and op this lane's path is parked at
     uint32_t draws = 0;
-    if (PARK) {
-        ps.start(ro, rd, 0.f, 0.f);
-        ps.m.begin(NONE, ro, rd, 0.f, 0.f, NONE);
-    }
+    if (PARK) pa.init(lds_stack + a.stack_words * blockDim.x);
     // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
     // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
     for (;;) {
@@ -182,10 +181,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
                 bounce = 0;
                 path_active = true;
                 cnt.samples++;
-                if (PARK) {
-                    draws = 0;
-                    ps.start(ro, rd, 0.001f, kF32Max);
-                }
+                if (PARK) draws = 0;
             }
             chunk_pos += take;
             exhausted = chunk_pos == chunk_end && chunk_end == a.n_paths;  // the counter only grows
@@ -196,7 +192,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
         }
         // ---- one ray_color call (render.rs:15-41) for every lane that has a path
         const bool run = path_active && depth_left != 0;
-        const bool was_parked = PARK && ps.parked;
+        const bool was_parked = PARK && park != NONE;
         if (run && !was_parked) cnt.rays++;
         Rng g;
         g.start(a.seed, pixel, sample, bounce);
@@ -208,11 +204,9 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
             if (g.n & 3u) g.refill();
             const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !was_parked)));
             const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
-            traverse_parking<COUNT>(sc, ro, rd, time, run, ps, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt);
+            traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt, t, ref);
             draws = g.n;
-            t = ps.tmax;
-            ref = ps.cur;
-            parked = run && ps.parked;
+            parked = run && park != NONE;
         } else {
             traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
         }
@@ -227,10 +221,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
                 thr = thr * b.weight;
                 depth_left -= 1;
                 bounce += 1;
-                if (PARK) {
-                    draws = 0;
-                    ps.start(ro, rd, 0.001f, kF32Max);
-                }
+                if (PARK) draws = 0;
             } else {
                 terminal = b.terminal;
             }
@@ -491,9 +482,9 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
     uint32_t p = 0, depth_left = 0, pixel = 0, sample = 0, draws = 0;
     f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(1.f, 1.f, 1.f), thr = mk3(0.f, 0.f, 0.f);
     float time = 0.f;
-    ProgState ps;
-    ps.start(ro, rd, 0.f, 0.f);
-    ps.m.begin(NONE, ro, rd, 0.f, 0.f, NONE);
+    ParkArea pa;
+    pa.init(lds_stack + a.stack_words * blockDim.x);
+    uint32_t park = NONE;  // the slot and op this lane's path is parked at
     for (;;) {
         const uint64_t idle = __ballot(!have);
         if (!exhausted && idle != 0) {
@@ -518,7 +509,6 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                 wf_path_key(a, p, pixel, sample);
                 have = true;
                 draws = 0;
-                ps.start(ro, rd, 0.001f, kF32Max);
             }
         }
         if (!__any(have)) {
@@ -531,28 +521,29 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
         // with the deepest descents are parked in their subtree rather than waited for (traverse_parking):
         // they finish it in later turns, beside the lanes that enter it then, unless the wave has little else to do.
         const bool run = have && depth_left != 0;
-        if (run && !ps.parked) cnt.rays++;
+        if (run && park == NONE) cnt.rays++;
         Rng g;
         g.start(a.seed, pixel, sample, a.max_depth - depth_left);
         g.n = draws;
         if (g.n & 3u) g.refill();
-        const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !ps.parked)));
+        const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && park == NONE)));
         const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
-        traverse_parking<COUNT>(sc, ro, rd, time, run, ps, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt);
+        float t_hit;
+        uint32_t ref_hit;
+        traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt, t_hit, ref_hit);
         draws = g.n;
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
-        const bool parked = run && ps.parked;
+        const bool parked = run && park != NONE;
         if (run && !parked) {
             Bounce b;
-            go_on = shade(sc, ro, rd, time, ps.tmax, ps.cur, ps.cur == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ps.cur), g, b);
+            go_on = shade(sc, ro, rd, time, t_hit, ref_hit, ref_hit == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref_hit), g, b);
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
                 thr = thr * b.weight;
                 depth_left -= 1;
                 draws = 0;
-                ps.start(ro, rd, 0.001f, kF32Max);
             } else {
                 terminal = b.terminal;
             }
