@@ -313,6 +313,16 @@ int rr_scene_info_get(rr_context* ctx, rr_scene_info* out);
 int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min, float t_max,
                     uint64_t seed, rr_hit* out_hits);
 
+/* Texture::get_color(u, v, p) (texture.rs:96-103) on the device for caller-supplied arguments, or, of a noise
+ * texture, Perlin::turb(p, depth) (perlin.rs:87-98) or Perlin::noise(p) (perlin.rs:47-86) alone: the functions the
+ * shading kernels evaluate, for parity checks.  textures: n indices into rr_flat_scene.textures; uvp: n x 5 f32
+ * (u, v, p.x, p.y, p.z); out_rgb: n x 3 f32 (turbulence and noise in all three).  Host memory.            */
+#define RR_EVAL_COLOR 0u
+#define RR_EVAL_TURB 1u
+#define RR_EVAL_NOISE 2u
+int rr_eval_textures(rr_context* ctx, uint32_t n, const uint32_t* textures, const float* uvp, uint32_t what,
+                     float* out_rgb);
+
 /* Render slices [slice_begin, slice_end) of the image; replaces the parallel
  * loop of render_multi (render.rs:135-151) and render_worker (render.rs:89-124).
  * All output pointers are DEVICE pointers owned by the caller, any of the

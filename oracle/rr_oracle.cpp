@@ -740,34 +740,51 @@ void rro_camera_ray(const rr_flat_scene* s, const rr_render_params* p, uint32_t 
     out[0] = r.o.x, out[1] = r.o.y, out[2] = r.o.z, out[3] = r.d.x, out[4] = r.d.y, out[5] = r.d.z, out[6] = r.tm;
 }
 
-// Same contract as rr_primary_hits (include/rr_hip.h), computed on the CPU.
+// Same contract as rr_primary_hits (include/rr_hip.h), computed on the CPU.  Rays are independent (a medium's draws are
+// keyed by the ray's index), so they are shared out over the host's cores, up to 16.
 int rro_primary_hits(const rr_flat_scene* s, uint32_t n, const float* rays, float t_min, float t_max, uint64_t seed,
                      rr_hit* out, rr_counters* counters) {
     if (!s || (!rays && n) || (!out && n)) return RR_E_INVALID;
-    rr_counters local{};
     const rr_list& root = s->lists[RR_REF_INDEX(s->root)];
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* q = rays + static_cast<size_t>(i) * 7;
-        Ray r{from(q), from(q + 3), q[6]};
-        Philox g;
-        g.start(seed, i, 0, 0);
-        Ctx c{s, &g, counters ? &local : nullptr};
-        Hit h;
-        rr_hit& o = out[i];
-        std::memset(&o, 0, sizeof(o));
-        if (hit_children(c, s->child_refs + root.first_child, root.n_children, r, t_min, t_max, h)) {
-            o.prim_id = h.prim;
-            o.material = h.mat;
-            o.t = h.t;
-            o.point[0] = h.p.x, o.point[1] = h.p.y, o.point[2] = h.p.z;
-            o.normal[0] = h.n.x, o.normal[1] = h.n.y, o.normal[2] = h.n.z;
-            o.u = h.u, o.v = h.v;
-            o.front_face = h.front ? 1u : 0u;
-        } else {
-            o.prim_id = -1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint32_t n_threads = n < 256 ? 1u : std::max(1u, std::min(16u, hw ? hw : 1u));
+    std::vector<rr_counters> tc(n_threads);
+    std::atomic<uint32_t> next{0};
+    auto worker = [&](uint32_t tid) {
+        rr_counters local{};
+        for (;;) {
+            const uint32_t begin = next.fetch_add(64);
+            if (begin >= n) break;
+            for (uint32_t i = begin; i < std::min(n, begin + 64u); ++i) {
+                const float* q = rays + static_cast<size_t>(i) * 7;
+                Ray r{from(q), from(q + 3), q[6]};
+                Philox g;
+                g.start(seed, i, 0, 0);
+                Ctx c{s, &g, counters ? &local : nullptr};
+                Hit h;
+                rr_hit& o = out[i];
+                std::memset(&o, 0, sizeof(o));
+                if (hit_children(c, s->child_refs + root.first_child, root.n_children, r, t_min, t_max, h)) {
+                    o.prim_id = h.prim;
+                    o.material = h.mat;
+                    o.t = h.t;
+                    o.point[0] = h.p.x, o.point[1] = h.p.y, o.point[2] = h.p.z;
+                    o.normal[0] = h.n.x, o.normal[1] = h.n.y, o.normal[2] = h.n.z;
+                    o.u = h.u, o.v = h.v;
+                    o.front_face = h.front ? 1u : 0u;
+                } else {
+                    o.prim_id = -1;
+                }
+            }
         }
-    }
-    if (counters) add_counters(*counters, local);
+        tc[tid] = local;
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : pool) t.join();
+    if (counters)
+        for (auto& c : tc) add_counters(*counters, c);
     return RR_OK;
 }
 

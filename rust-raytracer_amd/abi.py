@@ -27,6 +27,7 @@ FLAG_COUNT_PRODUCTION = 32
 N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
+EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
 
 
 def ref(tag, index):
@@ -175,6 +176,7 @@ HIP_PROTOTYPES = {
     "rr_scene_upload": (C.c_int, [vp, P(FlatScene)]),
     "rr_scene_info_get": (C.c_int, [vp, P(SceneInfo)]),
     "rr_primary_hits": (C.c_int, [vp, u32, f3, f32, f32, u64, P(Hit)]),
+    "rr_eval_textures": (C.c_int, [vp, u32, P(u32), f3, u32, f3]),
     "rr_render_device": (C.c_int, [vp, P(RenderParams), vp, vp, vp, vp, vp]),
     "rr_render_device_noalloc": (C.c_int, [vp, P(RenderParams), vp, vp, vp, vp, vp]),
     "rr_render": (C.c_int, [vp, P(RenderParams), P(u8), f3, f3, f3, P(Counters)]),

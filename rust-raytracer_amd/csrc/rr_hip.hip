@@ -219,6 +219,25 @@ __global__ void __launch_bounds__(256) k_primary_hits(DevScene sc, uint32_t n, c
     of[11] = 0.f;
 }
 
+// Texture::get_color (texture.rs:96-103), Perlin::turb (perlin.rs:87-98) or Perlin::noise (perlin.rs:47-86) for caller-supplied
+// arguments: what the shading kernels evaluate, on its own.
+__global__ void __launch_bounds__(256) k_eval_textures(DevScene sc, uint32_t n, const uint32_t* __restrict__ tex, const float* __restrict__ uvp,
+                                                        uint32_t what, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = uvp + static_cast<uint64_t>(i) * 5u;
+    const f3 p = mk3(q[2], q[3], q[4]);
+    f3 c;
+    if (what == RR_EVAL_COLOR) {
+        c = texture_color(sc, tex[i], q[0], q[1], p);
+    } else {
+        const DevTexture& t = sc.k->textures[tex[i]];
+        const float v = what == RR_EVAL_TURB ? perlin_turb(sc, t.index, p, t.depth) : perlin_noise(sc, t.index, p);
+        c = mk3(v, v, v);
+    }
+    out[3u * i] = c.x, out[3u * i + 1u] = c.y, out[3u * i + 2u] = c.z;
+}
+
 // render.rs:102-119 per slice, summed over the slices in slice order (render.rs:141-150).
 __global__ void __launch_bounds__(256) k_resolve(const float* __restrict__ slice_sums, uint32_t n_slices_here, uint64_t n_elems,
                                                  float scale, float n_threads, float* __restrict__ resolved,
@@ -294,6 +313,7 @@ struct rr_context {
     rr_scene_info info{};
     // ref → prim_id tables for rr_primary_hits (host side)
     std::vector<uint32_t> id_sphere, id_msphere, id_rect, id_tri, id_medium;
+    std::vector<uint32_t> tex_types;  // RR_TEX_* per texture of the scene (argument checks of rr_eval_textures)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int max_dynamic_lds = 0;
@@ -1206,8 +1226,10 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         materials[i] = dm;
     }
     std::vector<DevTexture> textures(s->n_textures);
+    ctx->tex_types.resize(s->n_textures);
     for (uint32_t i = 0; i < s->n_textures; ++i) {
         const rr_texture& t = s->textures[i];
+        ctx->tex_types[i] = t.type;
         DevTexture d{};
         d.type = t.type;
         d.index = t.index;
@@ -1491,6 +1513,42 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
 }  // namespace
 
 extern "C" {
+
+int rr_eval_textures(rr_context* ctx, uint32_t n, const uint32_t* textures, const float* uvp, uint32_t what, float* out_rgb) {
+    if (!ctx || (n && (!textures || !uvp || !out_rgb))) return fail(RR_E_INVALID, "rr_eval_textures: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_eval_textures: no scene uploaded");
+    if (what > RR_EVAL_NOISE) return fail(RR_E_INVALID, "rr_eval_textures: unknown quantity");
+    if (n == 0) return RR_OK;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (textures[i] >= ctx->tex_types.size()) return fail(RR_E_INVALID, "rr_eval_textures: texture outside the scene's table");
+        if (what != RR_EVAL_COLOR && ctx->tex_types[textures[i]] != RR_TEX_NOISE)
+            return fail(RR_E_INVALID, "rr_eval_textures: turbulence and noise are asked of a noise texture");
+    }
+    if (int rc = set_device(ctx)) return rc;
+    uint32_t* d_tex = nullptr;
+    float *d_in = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        if (d_tex) (void)hipFree(d_tex);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&d_tex, static_cast<size_t>(n) * 4)) != hipSuccess || (e = hipMalloc(&d_in, static_cast<size_t>(n) * 20)) != hipSuccess ||
+        (e = hipMalloc(&d_out, static_cast<size_t>(n) * 12)) != hipSuccess ||
+        (e = hipMemcpy(d_tex, textures, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_in, uvp, static_cast<size_t>(n) * 20, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return fail(RR_E_HIP, std::string("rr_eval_textures: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_eval_textures, dim3((n + 255u) / 256u), dim3(256), 0, 0, ctx->sc, n, d_tex, d_in, what, d_out);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(out_rgb, d_out, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost)) != hipSuccess) {
+        cleanup();
+        return fail(RR_E_HIP, std::string("rr_eval_textures: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return RR_OK;
+}
 
 int rr_render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums, void* d_resolved, void* d_linear,
                      void* d_counters, void* hip_stream) {

@@ -86,6 +86,17 @@ class Context:
                                        out.ctypes.data_as(C.POINTER(abi.Hit))))
         return out
 
+    def eval_textures(self, textures, uvp, what=abi.EVAL_COLOR):
+        """Texture::get_color / Perlin::turb / Perlin::noise on the device for n x (u, v, px, py, pz) -> n x 3."""
+        tex = np.ascontiguousarray(textures, dtype=np.uint32).reshape(-1)
+        uvp = np.ascontiguousarray(uvp, dtype=np.float32).reshape(-1, 5)
+        assert len(tex) == len(uvp)
+        out = np.zeros((len(tex), 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        _check(self._l.rr_eval_textures(self._h, len(tex), tex.ctypes.data_as(C.POINTER(C.c_uint32)), uvp.ctypes.data_as(fp), what,
+                                        out.ctypes.data_as(fp)))
+        return out
+
     def render(self, params, slice_sums=True):
         """Synchronous render into host arrays → dict(rgb8, resolved, linear, slice_sums, counters)."""
         h, w = max(0, params.rows), params.width  # (a reversed row range is the library's to report)

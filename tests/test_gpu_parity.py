@@ -292,6 +292,60 @@ def test_paths_match_the_numpy_restatement(gpu_ctx):
     compare_samples(got, gold, 0.985)
 
 
+def test_device_perlin_and_textures_match_the_fixture_and_the_oracle(gpu_ctx):
+    """Perlin::noise and Perlin::turb on the device against the numpy restatement's fixture (tests/golden/perlin.npz: table and
+    128 points, bit for bit: the functions are plain f32 arithmetic and integer table look-ups), and Texture::get_color of all
+    four texture kinds against the C++ oracle on 4 000 random arguments (checker and noise end in a sin: 2 ulp)."""
+    fx = np.load(f"{G.GOLDEN_DIR}/perlin.npz")
+    b = host.SceneBuilder(5)
+    img = np.random.default_rng(7).integers(0, 256, (9, 13, 3), dtype=np.uint8)
+    texs = [b.noise(4.0, 7), b.solid_color((0.1, 0.2, 0.3)), b.checkered((0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), b.load_image_rgb8(img)]
+    for t in texs:
+        b.add(b.sphere((0, 0, 0), 1.0, b.lambertian(t)))
+    b.set_camera((0, 0, -10), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+    flat = b.flatten()
+    kinds = [flat.textures[i].type for i in range(flat.n_textures)]
+    assert sorted(kinds) == [abi.TEX_SOLID, abi.TEX_CHECKERED, abi.TEX_NOISE, abi.TEX_IMAGE]
+    noise_tex = kinds.index(abi.TEX_NOISE)
+    pn = flat.perlin[flat.textures[noise_tex].index]  # the fixture's table in place of the builder's
+    for i in range(256):
+        for a in range(3):
+            pn.ranvec[i][a] = fx["ranvec"][i, a]
+        pn.perm_x[i], pn.perm_y[i], pn.perm_z[i] = int(fx["perms"][0, i]), int(fx["perms"][1, i]), int(fx["perms"][2, i])
+    gpu_ctx.upload(flat)
+    n = len(fx["points"])
+    uvp = np.concatenate([np.zeros((n, 2), dtype=np.float32), fx["points"]], axis=1)
+    tex = np.full(n, noise_tex, dtype=np.uint32)
+    assert np.array_equal(gpu_ctx.eval_textures(tex, uvp, abi.EVAL_NOISE)[:, 0], fx["noise"])
+    assert np.array_equal(gpu_ctx.eval_textures(tex, uvp, abi.EVAL_TURB)[:, 0], fx["turb"])
+    # far, huge and non-finite points go through the saturating float-to-integer casts of perlin.rs:69-71
+    odd = np.array([[1e9, -1e9, 3e9], [1e20, -1e20, 5.5], [-0.0, 255.999, 256.0], [np.inf, 1.0, 2.0], [np.nan, 0.5, -7.25], [-3e38, 3e38, 0.1]], dtype=np.float32)
+    uvo = np.concatenate([np.zeros((len(odd), 2), dtype=np.float32), odd], axis=1)
+    got = gpu_ctx.eval_textures(np.full(len(odd), noise_tex, dtype=np.uint32), uvo, abi.EVAL_NOISE)[:, 0]
+    want = np.array([O.lib().rro_perlin_noise(C.byref(pn), abi.vec3(q)) for q in odd], dtype=np.float32)
+    assert np.array_equal(got, want, equal_nan=True)
+    rng = np.random.default_rng(11)
+    m = 4000
+    uvp = np.concatenate([rng.uniform(-0.2, 1.2, (m, 2)), rng.normal(size=(m, 3)) * 10.0 ** rng.uniform(-1, 2.5, (m, 1))], axis=1).astype(np.float32)
+    tex = rng.integers(0, flat.n_textures, m).astype(np.uint32)
+    got = gpu_ctx.eval_textures(tex, uvp)
+    want = np.zeros((m, 3), dtype=np.float32)
+    out = (C.c_float * 3)()
+    for i in range(m):
+        O.lib().rro_texture_color(C.byref(flat), int(tex[i]), float(uvp[i, 0]), float(uvp[i, 1]), abi.vec3(uvp[i, 2:]), out)
+        want[i] = out[:]
+    exact = np.isin(tex, [kinds.index(abi.TEX_SOLID), kinds.index(abi.TEX_IMAGE)])
+    assert np.array_equal(got[exact], want[exact])
+    # a checker cell flips where the product of sines is within rounding of zero, and sin of a large argument differs in its
+    # last bits between the two math libraries: all but a handful of samples agree
+    close = np.isclose(got, want, rtol=0, atol=3e-6).all(axis=1)
+    assert close.mean() > 0.995, close.mean()
+    with pytest.raises(device.DeviceError, match="noise texture"):
+        gpu_ctx.eval_textures([kinds.index(abi.TEX_SOLID)], [[0, 0, 1, 2, 3]], abi.EVAL_TURB)
+    with pytest.raises(device.DeviceError, match="outside"):
+        gpu_ctx.eval_textures([99], [[0, 0, 1, 2, 3]])
+
+
 PRESETS = ["default_scene", "random_spheres", "random_moving_spheres", "two_spheres", "two_perlin_spheres", "earth", "rect_light",
            "cornell_box", "cornell_smoke", "cornell_pedestal", "final_scene"]
 
@@ -545,34 +599,38 @@ def test_full_size_cornell_configuration(gpu_ctx):
     ref = O.render(flat, O.make_params(600, 600, 16, n_slices=8, max_depth=200, seed=77), n_threads=16)
     m_gpu, m_ref = r["linear"].mean() / 1000.0, ref["linear"].mean() / 16.0
     assert abs(m_gpu - m_ref) < 0.01 * m_ref, (m_gpu, m_ref)
-    # per-pixel: the 1000-spp image is the converged version of the 16-spp one
-    rmse = np.sqrt(np.mean((r["linear"] / 1000.0 - ref["linear"] / 16.0) ** 2))
-    assert rmse < 0.35, rmse
+    # per pixel: the 1000-spp image is the converged version of the 16-spp one.  The oracle's two 8-spp halves (its slices,
+    # independent estimates of every pixel) give the noise of its 16-spp mean: var(mean16) ~ (a - b)^2 / 4, and the GPU
+    # image's own noise is 1/62 of that.  The mean squared difference must sit at that level, not merely below a constant.
+    a, b2 = ref["slice_sums"][:4].sum(axis=0) / 8.0, ref["slice_sums"][4:].sum(axis=0) / 8.0
+    noise_var = float(np.mean((a - b2) ** 2) / 4.0)
+    mse = float(np.mean((r["linear"] / 1000.0 - ref["linear"] / 16.0) ** 2))
+    assert 0.7 * noise_var < mse < 1.4 * noise_var, (mse, noise_var)
 
 
-@pytest.mark.parametrize("name,depth", [("suzanne", 100), ("final", 50)])
-def test_full_size_bvh_configurations(gpu_ctx, name, depth):
-    """The BVH configurations at their full image size and 1000 spp (several batches of the wavefront pipeline, two
-    workspaces in turns), through properties that do not need the oracle: every sample is traced, reruns are identical,
+@pytest.mark.parametrize("name,depth,spp", [("suzanne", 100, 1000), ("final", 50, 10000)])
+def test_full_size_bvh_configurations(gpu_ctx, name, depth, spp):
+    """The BVH configurations at their full size (Suzanne 800x800 at 1000 spp, final_scene 800x800 at 10 000 spp: several
+    batches of samples), through properties that do not need the oracle: every sample is traced, reruns are identical,
     two halves of the slices rendered on their own add up to the whole render bit for bit, and the image energy equals
     that of a render with other random numbers within Monte-Carlo error."""
     b, flat, _ = config_scene(name)
     gpu_ctx.upload(flat)
     kw = dict(n_slices=8, max_depth=depth, seed=1)
-    whole = gpu_ctx.render(device.make_params(800, 800, 1000, **kw), slice_sums=False)
-    assert whole["counters"]["samples"] == 800 * 800 * 1000
+    whole = gpu_ctx.render(device.make_params(800, 800, spp, **kw), slice_sums=False)
+    assert whole["counters"]["samples"] == 800 * 800 * spp
     assert 1.5 < whole["counters"]["rays"] / whole["counters"]["samples"] < 5.0
     assert np.isfinite(whole["linear"]).all() and whole["rgb8"].max() > 100
-    again = gpu_ctx.render(device.make_params(800, 800, 1000, **kw), slice_sums=False)
+    again = gpu_ctx.render(device.make_params(800, 800, spp, **kw), slice_sums=False)
     assert np.array_equal(whole["rgb8"], again["rgb8"]) and np.array_equal(whole["linear"], again["linear"])
-    lo = gpu_ctx.render(device.make_params(800, 800, 1000, slice_begin=0, slice_end=4, **kw), slice_sums=False)
-    hi = gpu_ctx.render(device.make_params(800, 800, 1000, slice_begin=4, slice_end=8, **kw), slice_sums=False)
+    lo = gpu_ctx.render(device.make_params(800, 800, spp, slice_begin=0, slice_end=4, **kw), slice_sums=False)
+    hi = gpu_ctx.render(device.make_params(800, 800, spp, slice_begin=4, slice_end=8, **kw), slice_sums=False)
     assert lo["counters"]["samples"] + hi["counters"]["samples"] == whole["counters"]["samples"]
     assert lo["counters"]["rays"] + hi["counters"]["rays"] == whole["counters"]["rays"]
     assert np.allclose(lo["linear"] + hi["linear"], whole["linear"], rtol=1e-6, atol=1e-6)
     assert np.allclose(lo["resolved"] + hi["resolved"], whole["resolved"], rtol=1e-6, atol=1e-6)
     other = gpu_ctx.render(device.make_params(800, 800, 64, n_slices=8, max_depth=depth, seed=99), slice_sums=False)
-    m_whole, m_other = whole["linear"].mean() / 1000.0, other["linear"].mean() / 64.0
+    m_whole, m_other = whole["linear"].mean() / spp, other["linear"].mean() / 64.0
     assert abs(m_whole - m_other) < 0.02 * m_other, (m_whole, m_other)
 
 
@@ -601,6 +659,42 @@ def test_converged_images_agree_within_rmse(gpu_ctx, name, side, spp, depth):
         assert rmse_same <= 0.002, (name, ch, rmse_same)
         assert rmse_other <= 0.06, (name, ch, rmse_other)
     assert abs(float(a[ok].mean()) - float(o_[ok].mean())) <= 0.015 * float(o_[ok].mean())
+
+
+def test_config5_at_full_size(gpu_ctx):
+    """The 1 000 000-triangle height field with 100 000 spheres (one BVH of 1.1 M primitives, 20 levels) at 3840x2160:
+    closest hits of 20 000 rays (camera rays over the whole image and the adversarial set) identical to the oracle's, which
+    makes every visit of the reference (about a million records per ray: triangles accept any t), so the production
+    traversal's culling and visit skipping are checked at this density; then a render of the full image through size-independent
+    properties: every sample traced, reruns identical, bands of rows and slice halves compose bit for bit."""
+    b, flat, d = host.build_config_scene("mesh")
+    assert (flat.n_triangles, flat.n_spheres, d["width"], d["height"]) == (1_000_000, 100_000, 3840, 2160)
+    info = gpu_ctx.upload(flat)
+    assert info["bvh_nodes_by_class"][3] > 1_000_000  # culled against [0, inf): triangles below
+    W, H = 3840, 2160
+    p = O.make_params(W, H, 4, n_slices=1, seed=11)
+    pixels = [(int(i * (W - 1) / 119), int(j * (H - 1) / 99)) for j in range(100) for i in range(120)]
+    rays = np.concatenate([O.camera_rays(flat, p, pixels, sample=1), _stress_rays(flat, 8000, seed=21)])
+    assert len(rays) == 20_000
+    got = gpu_ctx.primary_hits(rays, seed=4)
+    want = O.primary_hits(flat, rays, seed=4)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+    compare_hits(got, want, exact_t=True)
+    assert (want["prim_id"] >= 0).mean() > 0.1
+    kw = dict(n_slices=2, max_depth=50, seed=1)
+    whole = gpu_ctx.render(device.make_params(W, H, 2, **kw))
+    assert whole["counters"]["samples"] == W * H * 2 and whole["counters"]["rays"] >= whole["counters"]["samples"]
+    assert np.isfinite(whole["linear"]).all() and whole["rgb8"].max() > 50
+    again = gpu_ctx.render(device.make_params(W, H, 2, **kw), slice_sums=False)
+    assert np.array_equal(whole["rgb8"], again["rgb8"]) and np.array_equal(whole["linear"], again["linear"])
+    top = gpu_ctx.render(device.make_params(W, H, 2, row_begin=0, row_end=1000, **kw))
+    rest = gpu_ctx.render(device.make_params(W, H, 2, row_begin=1000, row_end=H, **kw))
+    assert np.array_equal(np.concatenate([top["slice_sums"], rest["slice_sums"]], axis=1), whole["slice_sums"], equal_nan=True)
+    assert np.array_equal(np.concatenate([top["rgb8"], rest["rgb8"]]), whole["rgb8"])
+    lo = gpu_ctx.render(device.make_params(W, H, 2, slice_begin=0, slice_end=1, **kw))
+    hi = gpu_ctx.render(device.make_params(W, H, 2, slice_begin=1, slice_end=2, **kw))
+    assert np.array_equal(np.concatenate([lo["slice_sums"], hi["slice_sums"]]), whole["slice_sums"], equal_nan=True)
+    assert lo["counters"]["rays"] + hi["counters"]["rays"] == whole["counters"]["rays"]
 
 
 # ------------------------------------------------------------------ edge cases
