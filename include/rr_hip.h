@@ -387,6 +387,29 @@ int rr_cast_u8_device(rr_context* ctx, const void* d_resolved, void* d_rgb8, uin
  * Synchronises with that kernel.                                            */
 int rr_last_kernel_ms(rr_context* ctx, float* ms);
 
+/* ------------------------------------------------- several GPUs, one host thread
+ * One render_multi job over the GPUs of a node from a host that is ONE process (a Rust or C program; the one-process-per-GPU
+ * form over torch.distributed / RCCL is rust_raytracer_amd/multi.py): the job is cut into bands of image rows and groups of
+ * sample slices (render.rs:130-140 shares out samples; rows share out pixels), every device renders its share on a stream of
+ * its own, the images of a band's slice groups are added on the band's first device (peer copies over xGMI where the devices
+ * can reach each other, then one add kernel: the mutex sum of render.rs:141-150, in group order), and every band is cast and
+ * copied to its rows of the host image.  The scene is replicated.  split:
+ *   RR_SPLIT_SLICES  device g renders slices [g*K/N, (g+1)*K/N) of the whole image;
+ *   RR_SPLIT_ROWS    device b renders rows [b*H/N, (b+1)*H/N) with every slice: bit for bit the single-device image;
+ *   RR_SPLIT_BOTH    B bands x G groups, B the smallest divisor of N with B*B >= N; device r is band r / G, group r % G.
+ * `job` describes the whole image (all slices, all rows).  A device may be listed more than once (each entry gets a context
+ * of its own), which is how a one-GPU machine tests the arithmetic.  Outputs are host buffers, any may be NULL; the call
+ * returns when they are filled.                                                                                          */
+#define RR_SPLIT_SLICES 0u
+#define RR_SPLIT_ROWS 1u
+#define RR_SPLIT_BOTH 2u
+typedef struct rr_multi rr_multi;
+int rr_multi_create(int n_devices, const int* devices, rr_multi** out);
+int rr_multi_destroy(rr_multi* m);
+int rr_multi_scene_upload(rr_multi* m, const rr_flat_scene* scene);
+int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, uint8_t* out_rgb8,
+                    float* out_resolved, float* out_linear, rr_counters* out_counters);
+
 const char* rr_last_error(void);
 
 #ifdef __cplusplus

@@ -251,14 +251,26 @@ pub fn render_hip(scene: SceneColliders, lights: Geometry, cam: Camera, backgrou
         root, light, camera, background: v3(background),
     };
 
-    let mut ctx = null_mut();
-    check(unsafe { rr_context_create(0, &mut ctx) });
-    check(unsafe { rr_scene_upload(ctx, &flat) });
     let k = num_cpus::get() as u32; // render.rs:129: the 8-bit image depends on the slice count (render.rs:102-119)
     let p = rr_render_params { width: img_width, height: img_height, samples_per_pixel: samples_per_pixel as u32, n_slices: k, slice_begin: 0,
                                slice_end: k, max_depth: max_depth as u32, seed: rand::random(), sample_offset: 0, flags: 0, row_begin: 0, row_end: 0 };
     let mut rgb = vec![0u8; (img_width * img_height * 3) as usize];
-    check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
-    unsafe { rr_context_destroy(ctx) };
+    let mut n_devices = 0;
+    check(unsafe { rr_device_count(&mut n_devices) });
+    if n_devices > 1 {
+        // every GPU of the node: bands of image rows (disjoint pixels, so the image is bit for bit the one-GPU image)
+        let devices: Vec<i32> = (0..n_devices).collect();
+        let mut multi = null_mut();
+        check(unsafe { rr_multi_create(n_devices, devices.as_ptr(), &mut multi) });
+        check(unsafe { rr_multi_scene_upload(multi, &flat) });
+        check(unsafe { rr_multi_render(multi, &p, RR_SPLIT_ROWS, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut()) });
+        unsafe { rr_multi_destroy(multi) };
+    } else {
+        let mut ctx = null_mut();
+        check(unsafe { rr_context_create(0, &mut ctx) });
+        check(unsafe { rr_scene_upload(ctx, &flat) });
+        check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
+        unsafe { rr_context_destroy(ctx) };
+    }
     ImageBuffer::from_raw(img_width, img_height, rgb).unwrap() // row 0 = top, as render.rs:119 writes it
 }

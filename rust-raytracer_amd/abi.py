@@ -28,6 +28,7 @@ N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
 EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
+SPLIT_SLICES, SPLIT_ROWS, SPLIT_BOTH = 0, 1, 2
 
 
 def ref(tag, index):
@@ -182,6 +183,10 @@ HIP_PROTOTYPES = {
     "rr_render": (C.c_int, [vp, P(RenderParams), P(u8), f3, f3, f3, P(Counters)]),
     "rr_cast_u8_device": (C.c_int, [vp, vp, vp, u64, vp]),
     "rr_last_kernel_ms": (C.c_int, [vp, f3]),
+    "rr_multi_create": (C.c_int, [C.c_int, P(C.c_int), P(vp)]),
+    "rr_multi_destroy": (C.c_int, [vp]),
+    "rr_multi_scene_upload": (C.c_int, [vp, P(FlatScene)]),
+    "rr_multi_render": (C.c_int, [vp, P(RenderParams), u32, P(u8), f3, f3, P(Counters)]),
     "rr_last_error": (C.c_char_p, []),
 }
 

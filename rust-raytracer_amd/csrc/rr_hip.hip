@@ -266,6 +266,12 @@ __global__ void __launch_bounds__(256) k_cast_u8(const float* __restrict__ src, 
     dst[e] = v;
 }
 
+// dst += src over n floats: the sum of the slice groups' images on the device that holds the band (render.rs:141-150).
+__global__ void __launch_bounds__(256) k_add_images(float* __restrict__ dst, const float* __restrict__ src, uint64_t n) {
+    const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e < n) dst[e] += src[e];
+}
+
 #include "rr_wavefront.h"
 
 // Device memory of rr_render_device_noalloc, the entry point that allocates nothing: the counter its waves claim paths
@@ -1629,6 +1635,180 @@ int rr_render(rr_context* ctx, const rr_render_params* p, uint8_t* out_rgb8, flo
         return hip_fail(e);
     if (out_counters && (e = hipMemcpy(out_counters, d_cnt, sizeof(rr_counters), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(e);
     cleanup();
+    return RR_OK;
+}
+
+
+// ------------------------------------------------------------------ several GPUs from one host thread
+struct rr_multi {
+    struct Dev {
+        int device = 0;
+        rr_context* ctx = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        float *sums = nullptr, *resolved = nullptr, *linear = nullptr, *stage = nullptr;
+        uint8_t* u8 = nullptr;
+        unsigned long long* counters = nullptr;
+        size_t sums_bytes = 0, image_bytes = 0;
+    };
+    std::vector<Dev> devs;
+};
+
+namespace {
+void cut(uint32_t n, uint32_t parts, uint32_t i, uint32_t* a, uint32_t* b) {
+    *a = static_cast<uint32_t>(static_cast<uint64_t>(i) * n / parts);
+    *b = static_cast<uint32_t>(static_cast<uint64_t>(i + 1) * n / parts);
+}
+int grow(void** p, size_t* have, size_t need) {
+    if (need <= *have && *p) return RR_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc(p, std::max<size_t>(need, 256)));
+    *have = need;
+    return RR_OK;
+}
+}  // namespace
+
+int rr_multi_create(int n_devices, const int* devices, rr_multi** out) {
+    if (!out || n_devices < 1 || !devices) return fail(RR_E_INVALID, "rr_multi_create: bad argument");
+    *out = nullptr;
+    rr_multi* m = new rr_multi();
+    m->devs.resize(static_cast<size_t>(n_devices));
+    for (int i = 0; i < n_devices; ++i) {
+        rr_multi::Dev& d = m->devs[static_cast<size_t>(i)];
+        d.device = devices[i];
+        int rc = rr_context_create(devices[i], &d.ctx);
+        if (rc == RR_OK && (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess))
+            rc = fail(RR_E_HIP, "rr_multi_create: stream or event creation failed");
+        if (rc == RR_OK && hipMalloc(reinterpret_cast<void**>(&d.counters), sizeof(rr_counters)) != hipSuccess)
+            rc = fail(RR_E_HIP, "rr_multi_create: hipMalloc failed");
+        if (rc != RR_OK) {
+            const std::string msg = g_err;
+            rr_multi_destroy(m);
+            return fail(rc, msg);
+        }
+    }
+    // bands are summed on their first device: let it read its partners' memory directly where the hardware can (xGMI)
+    for (const rr_multi::Dev& a : m->devs)
+        for (const rr_multi::Dev& b : m->devs)
+            if (a.device != b.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, a.device, b.device) == hipSuccess && can) {
+                    (void)hipSetDevice(a.device);
+                    (void)hipDeviceEnablePeerAccess(b.device, 0);  // (already enabled is not an error worth reporting)
+                    (void)hipGetLastError();
+                }
+            }
+    *out = m;
+    return RR_OK;
+}
+
+int rr_multi_destroy(rr_multi* m) {
+    if (!m) return RR_OK;
+    for (rr_multi::Dev& d : m->devs) {
+        if (!d.ctx) continue;  // creation stopped before this entry (its device may not even exist)
+        (void)hipSetDevice(d.device);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        for (void* p : {static_cast<void*>(d.sums), static_cast<void*>(d.resolved), static_cast<void*>(d.linear), static_cast<void*>(d.stage),
+                        static_cast<void*>(d.u8), static_cast<void*>(d.counters)})
+            if (p) (void)hipFree(p);
+        if (d.done) (void)hipEventDestroy(d.done);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.ctx) rr_context_destroy(d.ctx);
+    }
+    delete m;
+    return RR_OK;
+}
+
+int rr_multi_scene_upload(rr_multi* m, const rr_flat_scene* scene) {
+    if (!m || !scene) return fail(RR_E_INVALID, "rr_multi_scene_upload: NULL argument");
+    for (rr_multi::Dev& d : m->devs)
+        if (int rc = rr_scene_upload(d.ctx, scene)) return rc;
+    return RR_OK;
+}
+
+int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, uint8_t* out_rgb8, float* out_resolved, float* out_linear,
+                    rr_counters* out_counters) {
+    if (!m || !job) return fail(RR_E_INVALID, "rr_multi_render: NULL argument");
+    if (split > RR_SPLIT_BOTH) return fail(RR_E_INVALID, "rr_multi_render: unknown split");
+    if (job->width == 0 || job->height == 0 || job->n_slices == 0) return fail(RR_E_INVALID, "rr_multi_render: bad image size or slice count");
+    if (job->slice_begin != 0 || job->slice_end != job->n_slices || job->row_begin != 0 || (job->row_end != 0 && job->row_end != job->height))
+        return fail(RR_E_INVALID, "rr_multi_render: the job is a whole image (all slices, all rows); the shares are cut here");
+    const uint32_t world = static_cast<uint32_t>(m->devs.size());
+    // B bands of rows x G slice groups, B * G = world (the cut rust_raytracer_amd/multi.py makes for one process per GPU)
+    uint32_t bands = 1, groups = world;
+    if (split == RR_SPLIT_ROWS) bands = world, groups = 1;
+    if (split == RR_SPLIT_BOTH) {
+        for (bands = 1; bands * bands < world || world % bands != 0; ++bands) {}
+        groups = world / bands;
+    }
+    if (bands > job->height) return fail(RR_E_INVALID, "rr_multi_render: more bands than image rows");
+    const uint32_t W = job->width;
+    // ---- every device renders its share on its own stream; nothing below waits for a device until all are enqueued
+    std::vector<rr_render_params> share(world, *job);
+    for (uint32_t r = 0; r < world; ++r) {
+        rr_multi::Dev& d = m->devs[r];
+        rr_render_params& p = share[r];
+        cut(job->n_slices, groups, r % groups, &p.slice_begin, &p.slice_end);
+        cut(job->height, bands, r / groups, &p.row_begin, &p.row_end);
+        const uint32_t rows = p.row_end - p.row_begin, n_sl = p.slice_end - p.slice_begin;
+        const size_t image = static_cast<size_t>(W) * rows * 3u * sizeof(float);
+        HIP_TRY(hipSetDevice(d.device));
+        size_t keep = d.image_bytes;
+        if (int rc = grow(reinterpret_cast<void**>(&d.sums), &d.sums_bytes, image * std::max(n_sl, 1u))) return rc;
+        if (image > d.image_bytes || !d.resolved) {
+            for (float** q : {&d.resolved, &d.linear, &d.stage}) {
+                size_t have = keep;
+                if (int rc = grow(reinterpret_cast<void**>(q), &have, image)) return rc;
+            }
+            size_t have8 = keep / 4u;
+            if (int rc = grow(reinterpret_cast<void**>(&d.u8), &have8, image / 4u)) return rc;
+            d.image_bytes = image;
+        }
+        HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(rr_counters), d.stream));
+        if (int rc = rr_render_device(d.ctx, &p, d.sums, d.resolved, d.linear, d.counters, d.stream)) return rc;
+        HIP_TRY(hipEventRecord(d.done, d.stream));
+    }
+    // ---- per band: the slice groups' images are added onto the band's first device, in group order (the mutex sum of
+    // render.rs:141-150), then cast (render.rs:156-159) and copied to their rows of the host image
+    for (uint32_t b = 0; b < bands; ++b) {
+        rr_multi::Dev& root = m->devs[b * groups];
+        const rr_render_params& p = share[b * groups];
+        const uint64_t n = static_cast<uint64_t>(W) * (p.row_end - p.row_begin) * 3u;
+        HIP_TRY(hipSetDevice(root.device));
+        for (uint32_t g = 1; g < groups; ++g) {
+            rr_multi::Dev& src = m->devs[b * groups + g];
+            HIP_TRY(hipStreamWaitEvent(root.stream, src.done, 0));
+            for (int which = 0; which < 2; ++which) {
+                float* from = which == 0 ? src.resolved : src.linear;
+                float* to = which == 0 ? root.resolved : root.linear;
+                if (which == 1 && !out_linear) continue;
+                HIP_TRY(hipMemcpyPeerAsync(root.stage, root.device, from, src.device, n * sizeof(float), root.stream));
+                hipLaunchKernelGGL(k_add_images, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, root.stream, to, root.stage, n);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        const size_t row0 = static_cast<size_t>(p.row_begin) * W * 3u;
+        if (out_rgb8) {
+            if (int rc = rr_cast_u8_device(root.ctx, root.resolved, root.u8, n, root.stream)) return rc;
+            HIP_TRY(hipMemcpyAsync(out_rgb8 + row0, root.u8, n, hipMemcpyDeviceToHost, root.stream));
+        }
+        if (out_resolved) HIP_TRY(hipMemcpyAsync(out_resolved + row0, root.resolved, n * sizeof(float), hipMemcpyDeviceToHost, root.stream));
+        if (out_linear) HIP_TRY(hipMemcpyAsync(out_linear + row0, root.linear, n * sizeof(float), hipMemcpyDeviceToHost, root.stream));
+    }
+    rr_counters total{};
+    for (rr_multi::Dev& d : m->devs) {
+        HIP_TRY(hipSetDevice(d.device));
+        HIP_TRY(hipStreamSynchronize(d.stream));
+        rr_counters c{};
+        HIP_TRY(hipMemcpy(&c, d.counters, sizeof(c), hipMemcpyDeviceToHost));
+        uint64_t* t = reinterpret_cast<uint64_t*>(&total);
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(&c);
+        for (size_t k = 0; k < sizeof(rr_counters) / sizeof(uint64_t); ++k) t[k] += q[k];
+    }
+    if (out_counters) *out_counters = total;
     return RR_OK;
 }
 

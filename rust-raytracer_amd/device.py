@@ -128,6 +128,44 @@ class Context:
         return ms.value
 
 
+class MultiContext:
+    """Several GPUs driven from this one process (rr_multi_*): the in-process counterpart of rust_raytracer_amd.multi."""
+
+    def __init__(self, devices):
+        self._l = lib()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(self._l.rr_multi_create(len(devices), arr, C.byref(h)))
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rr_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, flat):
+        _check(self._l.rr_multi_scene_upload(self._h, C.byref(flat)))
+
+    def render(self, job, split=abi.SPLIT_SLICES):
+        """The whole job `job` (all slices, all rows) -> dict(rgb8, resolved, linear, counters) in host arrays."""
+        h, w = job.height, job.width
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        res = np.zeros((h, w, 3), dtype=np.float32)
+        lin = np.zeros((h, w, 3), dtype=np.float32)
+        cnt = abi.Counters()
+        fp = C.POINTER(C.c_float)
+        _check(self._l.rr_multi_render(self._h, C.byref(job), split, rgb.ctypes.data_as(C.POINTER(C.c_uint8)), res.ctypes.data_as(fp),
+                                       lin.ctypes.data_as(fp), C.byref(cnt)))
+        return dict(rgb8=rgb, resolved=res, linear=lin, counters=cnt.as_dict())
+
+
 def render_hip(flat, background_unused=None, *, max_depth, samples_per_pixel, img_width, img_height, n_slices=8, seed=1,
                device=0):
     """Drop-in for render_multi (src/render.rs:128): flattened scene in, H x W x 3 u8 image out.

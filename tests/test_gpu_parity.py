@@ -586,6 +586,45 @@ def test_bands_of_rows_and_slice_halves_recompose_the_image(gpu_ctx, name):
         gpu_ctx.render(device.make_params(W, H, spp, n_slices=K, row_begin=10, row_end=9))
 
 
+@pytest.mark.parametrize("name", ["cornell", "final"])
+def test_in_process_multi_device_entry(gpu_ctx, name):
+    """rr_multi_* (several GPUs driven by one host thread) with this box's one GPU listed one, two, three and four times:
+    every entry has a context, stream and buffers of its own, so the cuts, the peer copies, the adds and the row gather are the
+    ones of a node with that many GPUs.  Bands of rows give back the single-context image bit for bit; slice groups up to the
+    association of the f32 sum (the same cut as rust_raytracer_amd.multi makes for one process per GPU)."""
+    from rust_raytracer_amd import multi
+    b, flat, _ = config_scene(name)
+    gpu_ctx.upload(flat)
+    job = multi.job_params(90, 61, 24, 8, 30, 5)
+    whole = gpu_ctx.render(job)
+    for n_dev in (1, 2, 3, 4):
+        mc = device.MultiContext([0] * n_dev)
+        mc.upload(flat)
+        for split, part in ((abi.SPLIT_SLICES, "slices"), (abi.SPLIT_ROWS, "rows"), (abi.SPLIT_BOTH, "both")):
+            r = mc.render(job, split)
+            assert counts(r) == counts(whole), (n_dev, part)
+            if multi.grid(n_dev, part)[1] == 1:
+                assert np.array_equal(r["resolved"], whole["resolved"]) and np.array_equal(r["linear"], whole["linear"], equal_nan=True)
+                assert np.array_equal(r["rgb8"], whole["rgb8"])
+            else:
+                assert np.allclose(r["resolved"], whole["resolved"], rtol=1e-6, atol=1e-4) and np.allclose(r["linear"], whole["linear"], rtol=1e-6, atol=1e-6)
+                assert np.abs(r["rgb8"].astype(int) - whole["rgb8"].astype(int)).max() <= 1
+            again = mc.render(job, split)  # buffers and contexts are reused
+            assert np.array_equal(again["resolved"], r["resolved"]) and np.array_equal(again["rgb8"], r["rgb8"])
+        small = multi.job_params(33, 20, 8, 4, 10, 6)  # a smaller job on the same object
+        assert np.array_equal(mc.render(small, abi.SPLIT_ROWS)["rgb8"], gpu_ctx.render(small)["rgb8"])
+        mc.close()
+    mc = device.MultiContext([0, 0])
+    with pytest.raises(device.DeviceError, match="no scene"):
+        mc.render(job)
+    mc.upload(flat)
+    with pytest.raises(device.DeviceError, match="whole image"):
+        mc.render(device.make_params(90, 61, 24, n_slices=8, slice_begin=1, slice_end=8))
+    mc.close()
+    with pytest.raises(device.DeviceError):
+        device.MultiContext([0, 99])
+
+
 def test_full_size_cornell_configuration(gpu_ctx):
     """The headline benchmark configuration at full size (Cornell box, 600x600, 1000 spp, depth 200): every sample is traced,
     nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""

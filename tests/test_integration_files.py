@@ -23,7 +23,7 @@ def test_rust_declarations_cover_the_header():
     in_header = set(re.findall(r"^(?:int|const char\*) (rr_\w+)\(", header, flags=re.M))
     assert declared == in_header == set(abi.HIP_PROTOTYPES)
     structs = set(re.findall(r"pub struct (rr_\w+)", text))
-    assert structs == set(re.findall(r"^} (rr_\w+);", header, flags=re.M)) | {"rr_context"}
+    assert structs == set(re.findall(r"^} (rr_\w+);", header, flags=re.M)) | {"rr_context", "rr_multi"}
     for name in re.findall(r"^#define (RR_[A-Z_0-9]+) ", header, flags=re.M):
         if name not in ("RR_HIP_H",):
             assert f"pub const {name}:" in text, name
