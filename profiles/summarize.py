@@ -7,7 +7,7 @@
   <tag>_pmc_traffic.json              HBM bytes per sample and workload (read by bench.py for roofline.traffic)
 
 Only the kernels of the timed step count: bench.py's instrumented pass afterwards is cut off at the first dispatch of a
-counting kernel (k_render<true> / k_wf_paths<true> / k_wf_traverse<true> / k_wf_finish<true>).
+counting kernel (first template argument 1 or 2).
 
 usage: python profiles/summarize.py <tag> <workload>
 """
@@ -16,6 +16,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -25,17 +26,14 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{workload}")
 dst = os.path.join(ROOT, "profiles")
 
 
+KERNEL = re.compile(r"\b(k_render|k_wf_paths|k_wf_traverse|k_wf_finish)<(\d)")  # first template argument: 0 = production, 1 / 2 = counting builds
+
+
 def short(name):
-    if "k_render<false" in name:
-        return "k_render<false>"
-    if "k_render<true" in name:
-        return "k_render<true>"
-    if "k_wf_paths<false" in name:
-        return "k_wf_paths<false>"
-    if "k_wf_paths<true" in name:
-        return "k_wf_paths<true>"
-    for k in ("k_wf_traverse<false>", "k_wf_traverse<true>", "k_wf_finish<false>", "k_wf_finish<true>", "k_wf_shade",
-              "k_wf_init", "k_wf_accumulate", "k_resolve", "k_cast_u8"):
+    m = KERNEL.search(name)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    for k in ("k_wf_shade", "k_wf_init", "k_wf_accumulate", "k_resolve", "k_cast_u8"):
         if k in name:
             return k
     return None
@@ -48,7 +46,8 @@ def newest(pattern):
 
 
 def counting(name):
-    return "k_render<true" in name or "k_wf_paths<true" in name or "k_wf_traverse<true>" in name or "k_wf_finish<true>" in name
+    m = KERNEL.search(name)
+    return bool(m) and m.group(2) != "0"
 
 
 def last_json_line(path):
@@ -129,9 +128,17 @@ if pmc_bench:
         derived["salu_insts_per_wave_ray"] = round(tot["SQ_INSTS_SALU"] / (rays / 64.0), 1)
         derived["vmem_rd_insts_per_wave_ray"] = round(tot["SQ_INSTS_VMEM_RD"] / (rays / 64.0), 2)
         derived["lds_insts_per_wave_ray"] = round(tot["SQ_INSTS_LDS"] / (rays / 64.0), 2)
+    k_ms = pmc_bench["roofline"]["kernel_ms"]  # HIP events around the path-tracing kernels of the step the counters cover
+    main = max((k for k in pmc if k not in ("k_resolve", "k_cast_u8")), key=lambda k: pmc[k].get("SQ_INSTS_VALU", 0.0), default=None)
+    derived["kernel"] = main
+    if "SQ_INSTS_VALU" in tot and k_ms:
+        # a SIMD issues one wave64 vector instruction every 2 cycles (two passes of 32 lanes): 1024 SIMDs x 1.2 G/s at 2.4 GHz
+        derived["valu_issue_slot_frac"] = round(tot["SQ_INSTS_VALU"] / (1024 * 1.2e9 * k_ms * 1e-3), 4)
     if "SQ_THREAD_CYCLES_VALU" in tot and tot.get("SQ_ACTIVE_INST_VALU"):
         # both counters tick in units of 4 cycles; the ratio is the mean number of active lanes per VALU instruction
         derived["active_lanes_per_valu_inst"] = round(tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_ACTIVE_INST_VALU"], 2)
+    if "valu_issue_slot_frac" in derived and "active_lanes_per_valu_inst" in derived:
+        derived["lane_slot_frac"] = round(derived["valu_issue_slot_frac"] * derived["active_lanes_per_valu_inst"] / 64.0, 4)
     if tot.get("SQ_WAVE_CYCLES"):
         derived["wave_cycles_split"] = {k: round(tot[k] / tot["SQ_WAVE_CYCLES"], 4)
                                         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in tot}
@@ -165,6 +172,8 @@ if pmc_bench:
                 # the first dispatch of a wavefront kernel is the largest (every path of the batch is alive): the mean over
                 # dispatches is dominated by the many near-empty launches at the end of a bounce loop
                 derived.setdefault(name + "_first_dispatch", {})[k] = round(v[0], 3)
+    if main and "MeanOccupancyPerCU_mean_per_dispatch" in derived:
+        derived["waves_per_cu"] = derived["MeanOccupancyPerCU_mean_per_dispatch"].get(main)
     out["derived"] = derived
 json.dump(out, open(os.path.join(dst, f"{tag}_{workload}_summary.json"), "w"), indent=1)
 print(json.dumps(out.get("derived", {}), indent=1))
