@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--partition", default="slices", choices=["slices", "rows", "both"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--flags", type=int, default=0, help="RR_FLAG_* bits for the timed renders (kernel organisation)")
+    ap.add_argument("--semantics", default="reference", choices=["reference", "intended"],
+                    help="intended: the labelled alternative semantics (RR_SEMANTICS_INTENDED), never the default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting passes")
     args = ap.parse_args()
@@ -177,6 +179,8 @@ def main():
         spp = args.spp
     K = args.slices
     builder, flat, _ = host.build_config_scene(scene_name, seed=args.seed)
+    if args.semantics == "intended":
+        flat.semantics = abi.SEMANTICS_INTENDED
     ctx = device.Context(local_rank)
     info = ctx.upload(flat)
 
@@ -310,7 +314,7 @@ def main():
                                    + (f" ({spp} spp in {K} slices per GPU)" if args.scaling == "weak" and world > 1 else ""),
                        "scene": scene_name, "width": W, "height": H, "spp": job.samples_per_pixel, "slices": job.n_slices,
                        "max_depth": depth, "parallelism": f"{args.partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)",
-                       "seed": args.seed, "flags": args.flags, "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
+                       "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
             "rays_per_sample": round(total_rays / max(1, total_samples), 4),
             "kernel_ms_per_step": [round(x, 3) for x in kernel_ms],

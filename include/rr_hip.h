@@ -208,7 +208,23 @@ typedef struct rr_flat_scene {
     rr_light light;
     rr_camera camera;
     float background[3];
+    uint32_t semantics;        /* RR_SEMANTICS_*; 0 (a zeroed field) = the reference as it is at HEAD */
 } rr_flat_scene;
+
+/* Which intersection semantics the scene is traversed with.
+ *   RR_SEMANTICS_REFERENCE  the live code of src/collider.rs and src/aabb.rs, quirks included: what render_multi computes
+ *                           at HEAD, and what every parity claim of this library refers to.
+ *   RR_SEMANTICS_INTENDED   a labelled alternative, never the default: the three places where the live code departs from
+ *                           what it was written to do are put right -
+ *                             a BVH node whose first child misses goes on to its other child (the dead src/bvh.rs:28-44 has
+ *                             it; collider.rs:555-561 tests `left` again and never reaches `right`);
+ *                             AABB::intersect clips the ray on all three axes (aabb.rs:42 only clips on axes with a negative
+ *                             direction component);
+ *                             a triangle rejects hits outside [t_min, t_max] (collider.rs:627 ignores both).
+ *                           Everything else (materials, pdfs, media, instances) is unchanged.  With these the BVH returns the
+ *                           closest hit in range, as a linear list of the same primitives does.                              */
+#define RR_SEMANTICS_REFERENCE 0u
+#define RR_SEMANTICS_INTENDED 1u
 
 /* ---------------------------------------------------------- rendering */
 typedef struct rr_render_params {

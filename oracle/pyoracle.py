@@ -29,6 +29,11 @@ TAU = f32(2.0 * math.pi)
 
 np.seterr(all="ignore")
 
+# False: the reference as it is at HEAD.  True: the labelled "intended" semantics (RR_SEMANTICS_INTENDED in include/rr_hip.h):
+# a BVH node whose first child misses goes on to its other child (the dead src/bvh.rs:28-44), the slab test clips on all
+# three axes, a triangle rejects hits outside [t_min, t_max].  Set by the fixture generator and the tests, nowhere else.
+INTENDED = False
+
 
 def v3(x, y, z):
     return (f32(x), f32(y), f32(z))
@@ -371,13 +376,15 @@ def _hit_rect(g, r, t_min, t_max):  # collider.rs:344-359, 367-382, 405-420
     return h
 
 
-def _hit_triangle(g, r):  # collider.rs:627-667
+def _hit_triangle(g, r, t_min, t_max):  # collider.rs:627-667 (the reference ignores the range)
     ndd = dot(g.n, r.d)
     if abs(ndd) < f32(0.000001):
         return None
     d = -dot(g.n, g.p0)
     dist = -(dot(g.n, r.o) + d) / ndd
     if dist < f32(0):
+        return None
+    if INTENDED and (dist < t_min or dist > t_max):
         return None
     hp = add(r.o, scale(r.d, dist))
     for pa, pb in ((g.p0, g.p1), (g.p1, g.p2), (g.p2, g.p0)):
@@ -396,6 +403,9 @@ def aabb_hit(box, r, t_min, t_max):  # aabb.rs:37-52
         t1 = (hi[a] - r.o[a]) * inv_d
         if inv_d < f32(0):
             t0, t1 = t1, t0
+            t_min = t0 if t0 > t_min else t_min
+            t_max = t1 if t1 < t_max else t_max
+        elif INTENDED:  # the clipping the reference only does under the swap
             t_min = t0 if t0 > t_min else t_min
             t_max = t1 if t1 < t_max else t_max
         if t_max <= t_min:
@@ -427,7 +437,7 @@ def intersect(g, r, t_min, t_max, rnd=None):
     elif k in _RECT_AXES:
         h = _hit_rect(g, r, t_min, t_max)
     elif k == "triangle":
-        h = _hit_triangle(g, r)
+        h = _hit_triangle(g, r, t_min, t_max)
     elif k == "cuboid":
         return _hit_list(g.sides, r, t_min, t_max, rnd)
     elif k == "list":
@@ -494,7 +504,7 @@ def intersect(g, r, t_min, t_max, rnd=None):
             if lh is not None:
                 rh = intersect(g.right, r, t_min, lh.t, rnd)
                 return rh if rh is not None else lh
-            return intersect(g.left, r, t_min, t_max, rnd)  # `left` again, as in the reference
+            return intersect(g.right if INTENDED else g.left, r, t_min, t_max, rnd)  # `left` again, as in the reference
         rh = intersect(g.right, r, t_min, t_max, rnd)
         if rh is not None:
             lh = intersect(g.left, r, t_min, rh.t, rnd)

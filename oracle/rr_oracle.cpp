@@ -223,6 +223,21 @@ bool aabb_hit(const float bmin[3], const float bmax[3], const Ray& r, float t_mi
     return true;
 }
 
+// The labelled "intended" semantics (RR_SEMANTICS_INTENDED): the slab test on all three axes, as the test of aabb.rs:37-52
+// reads once the `if inv_d < 0.0` around the clipping is the swap it was meant to guard.
+bool aabb_hit_all_axes(const float bmin[3], const float bmax[3], const Ray& r, float t_min, float t_max) {
+    for (int a = 0; a < 3; ++a) {
+        float inv_d = 1.0f / get(r.d, a);
+        float t0 = (bmin[a] - get(r.o, a)) * inv_d;
+        float t1 = (bmax[a] - get(r.o, a)) * inv_d;
+        if (inv_d < 0.0f) std::swap(t0, t1);
+        t_min = t0 > t_min ? t0 : t_min;
+        t_max = t1 < t_max ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------ collider.rs
 bool hit_sphere_at(V3 center, float radius, const Ray& r, float t_min, float t_max, Hit& h, bool with_uv) {
     // collider.rs:278-301 (static) and 309-331 (moving: same roots, no uv)
@@ -282,13 +297,14 @@ bool hit_rect(const rr_rect& q, const Ray& r, float t_min, float t_max, Hit& h) 
     return true;
 }
 
-bool hit_triangle(const rr_triangle& tr, const Ray& r, Hit& h) {  // collider.rs:627-667 (t range ignored)
+bool hit_triangle(const rr_triangle& tr, const Ray& r, float t_min, float t_max, bool intended, Hit& h) {  // collider.rs:627-667 (t range ignored)
     V3 n = from(tr.normal), p0 = from(tr.p0), p1 = from(tr.p1), p2 = from(tr.p2);
     float n_dot_dir = dot(n, r.d);
     if (std::fabs(n_dot_dir) < 0.000001f) return false;
     float d = -dot(n, p0);
     float dist = -(dot(n, r.o) + d) / n_dot_dir;
     if (dist < 0.0f) return false;
+    if (intended && (dist < t_min || dist > t_max)) return false;  // RR_SEMANTICS_INTENDED only: the range test the other intersectors make
     V3 hp = r.o + r.d * dist;
     if (dot(n, cross(p1 - p0, hp - p0)) < 0.0f) return false;
     if (dot(n, cross(p2 - p1, hp - p1)) < 0.0f) return false;
@@ -392,9 +408,10 @@ bool hit_instance(Ctx& c, const rr_instance& in, const Ray& r, float t_min, floa
 }
 
 bool hit_bvh(Ctx& c, const rr_bvh_node& nd, const Ray& r, float t_min, float t_max, Hit& out) {  // collider.rs:536-581
+    const bool intended = c.s->semantics == RR_SEMANTICS_INTENDED;
     if (nd.has_box) {
         if (c.cnt) c.cnt->box_tests++;
-        if (!aabb_hit(nd.bmin, nd.bmax, r, t_min, t_max)) return false;
+        if (!(intended ? aabb_hit_all_axes(nd.bmin, nd.bmax, r, t_min, t_max) : aabb_hit(nd.bmin, nd.bmax, r, t_min, t_max))) return false;
     }
     if (get(r.d, static_cast<int>(nd.axis)) >= 0.0f) {
         Hit left_hit;
@@ -407,8 +424,8 @@ bool hit_bvh(Ctx& c, const rr_bvh_node& nd, const Ray& r, float t_min, float t_m
             }
             return true;
         }
-        // the reference re-tests `left` here, never `right`
-        return hit_ref(c, nd.left, r, t_min, t_max, out);
+        // the reference re-tests `left` here, never `right`; the intended semantics go on to `right` (src/bvh.rs:28-34)
+        return hit_ref(c, intended ? nd.right : nd.left, r, t_min, t_max, out);
     } else {
         Hit right_hit;
         if (hit_ref(c, nd.right, r, t_min, t_max, right_hit)) {
@@ -451,7 +468,7 @@ bool hit_ref(Ctx& c, uint32_t ref, const Ray& r, float t_min, float t_max, Hit& 
             return hit_rect(s.rects[idx], r, t_min, t_max, out);
         case RR_TAG_TRIANGLE:
             if (c.cnt) c.cnt->prim_tests++, c.cnt->tri_tests++;
-            return hit_triangle(s.triangles[idx], r, out);
+            return hit_triangle(s.triangles[idx], r, t_min, t_max, s.semantics == RR_SEMANTICS_INTENDED, out);
         case RR_TAG_CUBOID:
             return hit_cuboid(c, s.cuboids[idx], r, t_min, t_max, out);
         case RR_TAG_MEDIUM:

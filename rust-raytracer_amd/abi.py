@@ -29,6 +29,7 @@ PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
 EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
 SPLIT_SLICES, SPLIT_ROWS, SPLIT_BOTH = 0, 1, 2
+SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
 
 
 def ref(tag, index):
@@ -122,7 +123,7 @@ class FlatScene(C.Structure):
                 _arr("child_refs", u32) + _arr("materials", Material) + _arr("textures", Texture) +
                 _arr("perlin", Perlin) + _arr("images", Image) +
                 [("n_image_bytes", u64), ("image_bytes", C.POINTER(u8)), ("root", u32), ("light", Light),
-                 ("camera", Camera), ("background", f32 * 3)])
+                 ("camera", Camera), ("background", f32 * 3), ("semantics", u32)])
 
 
 class RenderParams(C.Structure):

@@ -108,6 +108,7 @@ struct DevScene {  // kernel argument
     const uint32_t* child_refs;
     const RR_CONST_AS uint4* prog;  // scene program, 2 uint4 (one 32-byte op) per entry, terminated by OP_END
     float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
+    uint32_t intended;              // RR_SEMANTICS_INTENDED: the labelled alternative semantics (see include/rr_hip.h), 0 by default
     const RR_CONST_AS DevConst* k;
 };
 
@@ -338,14 +339,15 @@ __device__ __forceinline__ bool test_rect_axis(float a0, float a1, float b0, flo
     return !(out_of_range | outside);
 }
 
-__device__ __forceinline__ bool test_triangle(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& t) {
-    // collider.rs:627-661; the t range is not tested
+__device__ __forceinline__ bool test_triangle(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, float tmax, bool ranged, float& t) {
+    // collider.rs:627-661; the t range is not tested (`ranged`: it is, under the labelled intended semantics only)
     const f3 p0 = mk3(q0.x, q0.y, q0.z), p1 = mk3(q0.w, q1.x, q1.y), p2 = mk3(q1.z, q1.w, q2.x), n = mk3(q2.y, q2.z, q2.w);
     float ndd = dot3(n, d);
     if (fabsf(ndd) < 0.000001f) return false;
     float dd = -dot3(n, p0);
     float dist = -(dot3(n, o) + dd) / ndd;
     if (dist < 0.0f) return false;
+    if (ranged && (dist < tmin || dist > tmax)) return false;
     f3 hp = o + d * dist;
     if (dot3(n, cross3(p1 - p0, hp - p0)) < 0.0f) return false;
     if (dot3(n, cross3(p2 - p1, hp - p1)) < 0.0f) return false;
@@ -492,6 +494,12 @@ __device__ __forceinline__ bool node_box_pass(const DevScene& sc, const Trav& m,
     const float hi = fminf(fminf(m.tmax, nx ? fx : m.tmax), fminf(ny ? fy : m.tmax, nz ? fz : m.tmax));
     // (A bound that is NaN on entry — the t of a degenerate hit — stays NaN in the reference and
     // fails no comparison, where fmaxf/fminf would drop it.)
+    if (sc.intended) {
+        // the labelled intended semantics: every axis clips, and the box test itself is then the cull
+        const float lo3 = fmaxf(fmaxf(m.tmin, ex), fmaxf(ey, ez));
+        const float hi3 = fminf(fminf(m.tmax, fx), fminf(fy, fz));
+        return !(hi3 <= lo3) || __builtin_isunordered(m.tmin, m.tmax);
+    }
     bool pass = !(hi <= lo) || __builtin_isunordered(m.tmin, m.tmax);
     if (cls >= BVH_CLASS_CULL_RANGE && m.cull) {
         // All three slabs of the box grown by the margin, against the segment no accepted hit can lie
@@ -511,9 +519,23 @@ __device__ __forceinline__ bool node_box_pass(const DevScene& sc, const Trav& m,
 
 // What follows a passed box test (collider.rs:546-580): the first child by the sign of direction[axis], and the frame that
 // names what comes after it.  `left` and `right` are the node's words (child ref, and axis or class in the spare bits).
-__device__ __forceinline__ void node_descend(Trav& m, uint32_t idx, uint32_t left, uint32_t right, uint32_t cls, uint32_t* stk, uint32_t stride) {
+__device__ __forceinline__ void node_descend(const DevScene& sc, Trav& m, uint32_t idx, uint32_t left, uint32_t right, uint32_t cls, uint32_t* stk,
+                                             uint32_t stride) {
     const uint32_t l = left & REF_MASK, r = right & REF_MASK;
     const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
+    if (sc.intended) {
+        // the labelled intended semantics (src/bvh.rs:19-44): the other child follows the first after a hit and after a miss
+        // alike; a span-1 node's second visit is only left out where it cannot draw random numbers
+        if (cls >= BVH_CLASS_CULL_RANGE && l == r) {
+            m.node = l;
+        } else {
+            stk[m.sp * stride] = (dirpos ? r : l) | (m.hitf ? FW_FLAG : 0u);
+            m.sp += 1;
+            m.hitf = false;
+            m.node = dirpos ? l : r;
+        }
+        return;
+    }
     // In the culling classes evaluating the same child twice over the same or a smaller
     // range cannot change the outcome.  The reference-order counting build evaluates everything.
     const bool pure = cls >= BVH_CLASS_CULL_RANGE;
@@ -555,7 +577,7 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
             if (COUNT) cnt.box_tests++;
             pass = node_box_pass(sc, m, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), cls);
         }
-        if (pass) node_descend(m, idx, left, right, cls, stk, stride);
+        if (pass) node_descend(sc, m, idx, left, right, cls, stk, stride);
     }
 }
 
@@ -581,7 +603,7 @@ __device__ __forceinline__ void trav_leaf_simple(const DevScene& sc, Trav& m, Co
         } else if (tag == RR_TAG_TRIANGLE) {
             if (COUNT) cnt.tri_tests++;
             float t;
-            if (test_triangle(q0, q1, q2, m.o, m.d, t)) m.tmax = t, m.cur = node, m.hitf = true;
+            if (test_triangle(q0, q1, q2, m.o, m.d, m.tmin, m.tmax, sc.intended != 0u, t)) m.tmax = t, m.cur = node, m.hitf = true;
         } else if (tag == RR_TAG_RECT) {
             if (COUNT) cnt.rect_tests++;
             float t, ca, cb;
@@ -655,7 +677,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
         } else if (tag == RR_TAG_TRIANGLE) {
             if (COUNT) cnt.tri_tests++;
             float t;
-            if (test_triangle(q0, q1, q2, m.o, m.d, t)) {
+            if (test_triangle(q0, q1, q2, m.o, m.d, m.tmin, m.tmax, sc.intended != 0u, t)) {
                 m.tmax = t;
                 m.cur = node;
                 m.hitf = true;
@@ -899,7 +921,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
     } else if (tag == RR_TAG_TRIANGLE) {
         if (COUNT) cnt.tri_tests++;
         float t;
-        if (test_triangle(sc.tri[3 * idx], sc.tri[3 * idx + 1], sc.tri[3 * idx + 2], o, d, t)) {
+        if (test_triangle(sc.tri[3 * idx], sc.tri[3 * idx + 1], sc.tri[3 * idx + 2], o, d, tmin, tmax, sc.intended != 0u, t)) {
             tmax = t;
             cur = n;
         }
@@ -1204,7 +1226,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             }
             if (__any(enter)) {
                 const uint32_t left = __float_as_uint(sc.bvh[2 * ridx].w), right = __float_as_uint(sc.bvh[2 * ridx + 1].w);
-                if (enter) node_descend(m, ridx, left, right, cls, stk, stride);
+                if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
             }
             const bool in = enter || rejoin;
             uint32_t steps = 0;

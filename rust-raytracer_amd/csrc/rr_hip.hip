@@ -1070,6 +1070,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     if ((s->n_child_refs && !s->child_refs) || (s->n_materials && !s->materials) || (s->n_textures && !s->textures) ||
         (s->n_perlin && !s->perlin) || (s->n_images && !s->images) || (s->n_image_bytes && !s->image_bytes))
         return fail(RR_E_INVALID, "rr_scene_upload: a non-empty array has a NULL pointer");
+    if (s->semantics > RR_SEMANTICS_INTENDED) return fail(RR_E_INVALID, "rr_scene_upload: unknown semantics");
     if (RR_REF_TAG(s->root) != RR_TAG_LIST || RR_REF_INDEX(s->root) >= s->n_lists)
         return fail(RR_E_INVALID, "rr_scene_upload: root must be a list ref");
     for (uint32_t i = 0; i < s->n_materials; ++i) {
@@ -1143,6 +1144,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
             for (int a = 0; a < 3 && holds; ++a)
                 holds = static_cast<double>(n.bmin[a]) - 0.5 * cull_eps <= b.lo[a] && b.hi[a] <= static_cast<double>(n.bmax[a]) + 0.5 * cull_eps;
             if (holds) cls = b.has_tri ? BVH_CLASS_CULL_ANY_T : BVH_CLASS_CULL_RANGE;
+            // under the labelled intended semantics the class only says whether a repeated visit could draw random numbers
+            if (s->semantics == RR_SEMANTICS_INTENDED) cls = b.has_medium ? BVH_CLASS_REFERENCE : BVH_CLASS_CULL_RANGE;
         }
         bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, cls)));
         bvh_class[i] = static_cast<uint8_t>(cls);
@@ -1324,6 +1327,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // 2580-2610 Msamples/s, final_scene 1200 against 1155-1175, Cornell box with the Suzanne mesh 2175 against 2800-2830).
     ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4;
     ctx->root = to_dref(s->root);
+    ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
     ctx->info.wavefront = ctx->auto_pipeline ? 1u : 0u;

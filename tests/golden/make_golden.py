@@ -33,7 +33,9 @@ def make_rays(cam_args, n):
     return rays
 
 
-def make_scene(name):
+def make_scene(name, intended=False):
+    """intended: the labelled alternative semantics (RR_SEMANTICS_INTENDED) -> hits_<name>_intended.npz."""
+    P.INTENDED = intended
     fn, seed, n = G.SCENES[name]
     A = G.PyAdapter(seed)
     objs, cam = fn(A)
@@ -51,7 +53,9 @@ def make_scene(name):
             out[i] = (h.prim, h.t, h.p, h.n, h.u, h.v, 1 if h.front else 0)
     hits = int((out["prim_id"] >= 0).sum())
     print(f"{name}: {len(rays)} rays, {hits} hits, {n_prims} prims, {len(set(out['prim_id']))} distinct ids, {time.time() - t0:.1f} s")
-    np.savez_compressed(os.path.join(HERE, f"hits_{name}.npz"), rays=rays, hits=out, n_prims=n_prims, media_seed=G.MEDIA_SEED)
+    np.savez_compressed(os.path.join(HERE, f"hits_{name}{'_intended' if intended else ''}.npz"), rays=rays, hits=out, n_prims=n_prims,
+                        media_seed=G.MEDIA_SEED)
+    P.INTENDED = False
 
 
 def make_perlin():
@@ -79,11 +83,13 @@ def make_paths():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(G.SCENES) + ["perlin", "paths"]
+    names = sys.argv[1:] or list(G.SCENES) + [n + "_intended" for n in G.INTENDED_SCENES] + ["perlin", "paths"]
     for nm in names:
         if nm == "perlin":
             make_perlin()
         elif nm == "paths":
             make_paths()
+        elif nm.endswith("_intended"):
+            make_scene(nm[:-len("_intended")], intended=True)
         else:
             make_scene(nm)

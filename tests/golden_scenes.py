@@ -216,6 +216,10 @@ SCENES = {
 MEDIA_SEED = 77  # seed of the Philox streams that feed the constant media in the fixtures
 
 
+# scenes that also have a fixture under the labelled "intended" semantics (hits_<name>_intended.npz)
+INTENDED_SCENES = ["sphere_bvh", "hand_tree", "tri_mesh", "cuboid_bvh"]
+
+
 def build_host(name):
     """→ (adapter, FlatScene) of scene `name` built through the host library."""
     fn, seed, _ = SCENES[name]

@@ -45,6 +45,61 @@ def test_oracle_reproduces_golden_hits(built, name):
     assert (fx["hits"]["prim_id"] >= 0).sum() > 50
 
 
+def intended(flat):
+    """A copy of the flattened scene that asks for the labelled intended semantics (RR_SEMANTICS_INTENDED)."""
+    from rust_raytracer_amd import abi
+    c = abi.FlatScene.from_buffer_copy(flat)
+    c.semantics = abi.SEMANTICS_INTENDED
+    return c
+
+
+@pytest.mark.parametrize("name", G.INTENDED_SCENES)
+def test_oracle_reproduces_golden_hits_under_the_intended_semantics(built, name):
+    """The labelled alternative semantics (a BVH node whose first child misses goes on to the other, all-axis slab test,
+    triangles test the t range), restated twice like the reference's own: the C++ oracle against pyoracle's fixture."""
+    fx = np.load(f"{G.GOLDEN_DIR}/hits_{name}_intended.npz")
+    ref = np.load(f"{G.GOLDEN_DIR}/hits_{name}.npz")
+    A, flat = G.build_host(name)
+    got = O.primary_hits(intended(flat), fx["rays"], seed=int(fx["media_seed"]))
+    compare_hits(got, fx["hits"], exact_t=True)
+    assert np.array_equal(fx["rays"], ref["rays"])
+    # the reference's semantics lose hits behind the miss branch: the intended ones find at least as many, and differ
+    assert (fx["hits"]["prim_id"] >= 0).sum() >= (ref["hits"]["prim_id"] >= 0).sum()
+    if name != "cuboid_bvh":  # (every ray of that fixture looks down a direction whose miss branch is the correct one)
+        assert not np.array_equal(fx["hits"]["prim_id"], ref["hits"]["prim_id"])
+
+
+def test_intended_bvh_returns_what_a_linear_list_returns(built):
+    """Under the intended semantics a BVH is only an accelerator: the closest hit in range, as SceneColliders::intersect
+    (collider.rs:751-772) finds over the same spheres without it.  (Under the reference's semantics it is not: rays are lost.)"""
+    from rust_raytracer_amd import host
+    rng = np.random.default_rng(5)
+    centers = rng.uniform(-20, 20, (150, 3))
+    radii = rng.uniform(0.5, 3.0, 150)
+
+    def scene(with_bvh):
+        b = host.SceneBuilder(9)
+        m = b.lambertian(b.solid_color((0.5, 0.5, 0.5)))
+        items = [b.sphere(c, float(r), m) for c, r in zip(centers, radii)]
+        if with_bvh:
+            b.add(b.bvh_node(items))
+        else:
+            for g in items:
+                b.add(g)
+        b.set_camera((0, 0, -60), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+        return b, b.flatten()
+
+    (b1, tree), (b2, flat_list) = scene(True), scene(False)
+    rays = np.concatenate([rng.uniform(-30, 30, (4000, 3)), rng.normal(size=(4000, 3)), rng.uniform(0, 1, (4000, 1))], axis=1).astype(np.float32)
+    lin = O.primary_hits(flat_list, rays)
+    got = O.primary_hits(intended(tree), rays)
+    ref = O.primary_hits(tree, rays)
+    hit = lin["prim_id"] >= 0
+    assert hit.mean() > 0.15 and np.array_equal(got["prim_id"] >= 0, hit)
+    assert np.array_equal(got["t"][hit], lin["t"][hit]) and np.array_equal(got["point"][hit], lin["point"][hit])
+    assert ((ref["prim_id"] >= 0) & hit).sum() < hit.sum()  # the live semantics lose some of them (collider.rs:555-561)
+
+
 # ------------------------------------------------------------ whole paths
 def _paths_fixture():
     import golden_paths as GP

@@ -14,7 +14,7 @@ import rust_raytracer_amd  # noqa: F401
 from rust_raytracer_amd import abi, device, host
 import golden_scenes as G
 import oracle_lib as O
-from test_golden_cpu import compare_hits
+from test_golden_cpu import compare_hits, intended
 
 pytestmark = pytest.mark.gpu
 
@@ -215,6 +215,48 @@ def test_renders_of_random_scenes_agree_between_all_kernel_forms(gpu_ctx, seed):
     both = ~nan_got & ~nan_want
     assert both.mean() > 0.05, "too few samples without NaN to compare"
     assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.995
+
+
+# ------------------------------------------------- the labelled intended semantics
+@pytest.mark.parametrize("name", G.INTENDED_SCENES)
+def test_intended_semantics_match_golden_fixtures(gpu_ctx, name):
+    fx = np.load(f"{G.GOLDEN_DIR}/hits_{name}_intended.npz")
+    A, flat = G.build_host(name)
+    gpu_ctx.upload(intended(flat))
+    compare_hits(gpu_ctx.primary_hits(fx["rays"], seed=int(fx["media_seed"])), fx["hits"], exact_t=True)
+
+
+@pytest.mark.parametrize("name,kw", [("spheres", {}), ("suzanne", {}), ("final", {}), ("mesh", dict(n_triangles=20000, n_spheres=2000))])
+def test_intended_semantics_match_the_oracle_on_benchmark_scenes(gpu_ctx, name, kw):
+    """RR_SEMANTICS_INTENDED (never the default): hits identical to the oracle's under the same switch for camera rays and the
+    adversarial set, renders identical between all kernel organisations and in parity with the oracle's, and more geometry
+    found than under the reference's semantics (whose miss branch loses the right subtree, collider.rs:555-561)."""
+    b, flat, d = host.build_config_scene(name, seed=3, **kw)
+    fi = intended(flat)
+    gpu_ctx.upload(fi)
+    rays = _stress_rays(flat, 60_000, seed=9)
+    got, want = gpu_ctx.primary_hits(rays, seed=4), O.primary_hits(fi, rays, seed=4)
+    compare_hits(got, want, exact_t=(flat.n_media == 0))
+    ref = O.primary_hits(flat, rays, seed=4)
+    assert (want["prim_id"] >= 0).sum() > (ref["prim_id"] >= 0).sum()
+    kw2 = dict(n_slices=4, max_depth=20, seed=5)
+    base = gpu_ctx.render(device.make_params(64, 48, 8, **kw2))
+    for flags in (abi.FLAG_COUNTERS, abi.FLAG_COUNT_PRODUCTION, abi.FLAG_PERSISTENT, abi.FLAG_WAVEFRONT, abi.FLAG_PATHS):
+        other = gpu_ctx.render(device.make_params(64, 48, 8, flags=flags, **kw2))
+        assert np.array_equal(base["slice_sums"], other["slice_sums"], equal_nan=True), flags
+    assert_render_parity(base, O.render(fi, O.make_params(64, 48, 8, **kw2), n_threads=8), min_close=0.97)
+    gpu_ctx.upload(flat)
+    assert not np.array_equal(gpu_ctx.render(device.make_params(64, 48, 8, **kw2))["slice_sums"], base["slice_sums"], equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_intended_semantics_on_random_scenes(gpu_ctx, seed):
+    b, flat = _random_scene(20 + seed)
+    fi = intended(flat)
+    gpu_ctx.upload(fi)
+    rays = _stress_rays(flat, 40_000, seed=300 + seed)
+    rays[:, :3] *= 0.3
+    compare_hits(gpu_ctx.primary_hits(rays, seed=4), O.primary_hits(fi, rays, seed=4), exact_t=(flat.n_media == 0))
 
 
 # ------------------------------------------------------------ whole renders
