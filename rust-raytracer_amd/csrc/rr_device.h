@@ -969,6 +969,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
     uint32_t m_cur = NONE;
     const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
     Op next = prog[0];
+    asm volatile("" ::"s"(next.code));  // the first op has arrived before the loop: inside it only the fetch of the op after the current one is in flight
     uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
     for (;;) {
         // the op after this one is fetched while this one executes (the program ends in two OP_ENDs)
@@ -1180,7 +1181,7 @@ __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Tr
 template <int COUNT>
 __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, float tmin0, float tmax0, bool enabled,
                                                  uint32_t& park, ParkArea& pa, Rng& rng, uint32_t* stk, uint32_t stride, uint32_t park_below,
-                                                 uint32_t min_steps, Counts& cnt, float& t_hit, uint32_t& ref_hit) {
+                                                 uint32_t min_steps, uint32_t leaf_wait, Counts& cnt, float& t_hit, uint32_t& ref_hit) {
     ProgState s;
     s.start(wo, wd, tmin0, tmax0);
     uint32_t slot = park >> 24;
@@ -1191,6 +1192,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
     bool act = enabled && !s.parked;  // the lane executes the ops it comes to
     const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
     Op next = prog[0];
+    asm volatile("" ::"s"(next.code));  // the first op has arrived before the loop: inside it only the fetch of the op after the current one is in flight
     uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
     const WorldInRegs world{wo, wd, time};
     Counts& pcnt = cnt;
@@ -1234,11 +1236,15 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 const bool going = in && !m.finished();
                 const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
                 if (n == 0 || may_park(going, n, steps)) break;
-                if (going) {
-                    trav_node<COUNT>(sc, m, stk, stride, cnt);
-                    trav_leaf_simple<COUNT>(sc, m, cnt);
-                    trav_pop_simple(sc, m, stk, stride);
+                // A leaf move is the dearest of the three and usually only a few lanes are at a leaf: those wait, while other
+                // lanes can still move, until they are at least one in `leaf_wait` of the lanes descending (0: nobody waits).
+                if (going) trav_node<COUNT>(sc, m, stk, stride, cnt);
+                const bool at_leaf = going && trav_at_leaf(m);
+                const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
+                if (leaf_wait == 0u || n_leaf * leaf_wait >= n || !__any(going && !at_leaf)) {
+                    if (at_leaf) trav_leaf_simple<COUNT>(sc, m, cnt);
                 }
+                if (going) trav_pop_simple(sc, m, stk, stride);
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }

@@ -127,6 +127,9 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 #ifndef RR_WF_FINISH_PARK_MIN_FRESH
 #define RR_WF_FINISH_PARK_MIN_FRESH 8  // with the queue drained and fewer lanes than this starting a ray, nothing is parked
 #endif
+#ifndef RR_PATHS_LEAF_WAIT
+#define RR_PATHS_LEAF_WAIT 4u  // k_wf_paths: lanes at a leaf of a subtree wait until they are a quarter of the descending lanes (see traverse_parking)
+#endif
 #ifndef RR_PATHS_CHUNK
 #define RR_PATHS_CHUNK 512u  // paths a wave claims at a time
 #endif
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
             if (g.n & 3u) g.refill();
             const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !was_parked)));
             const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
-            traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt, t, ref);
+            traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
             draws = g.n;
             parked = run && park != NONE;
         } else {
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
         const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
         float t_hit;
         uint32_t ref_hit;
-        traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, cnt, t_hit, ref_hit);
+        traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, 0u, cnt, t_hit, ref_hit);
         draws = g.n;
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
