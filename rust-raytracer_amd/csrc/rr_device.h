@@ -472,6 +472,11 @@ struct Trav {
 // The machine is finished when m.node is NONE and the stack is empty.  A kernel is
 // free to schedule the moves of its 64 lanes as it likes (all lanes at nodes first, leaves when
 // enough lanes have one) as long as each lane's own sequence is node/leaf followed by pop.
+// All three words of a record are in registers from here on: without this the compiler moves the loads of the words only
+// some kinds of record use into the branches that use them, behind the first word's arrival, and a move waits for memory twice.
+__device__ __forceinline__ void records_arrived(const float4& q0, const float4& q1, const float4& q2) {
+    asm volatile("" ::"v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
+}
 __device__ __forceinline__ bool trav_at_node(const Trav& m) { return m.node != NONE && dtag(m.node) == RR_TAG_BVH; }
 __device__ __forceinline__ bool trav_at_leaf(const Trav& m) { return m.node != NONE && dtag(m.node) != RR_TAG_BVH; }
 
@@ -572,11 +577,10 @@ __device__ __forceinline__ void trav_node(const DevScene& sc, Trav& m, uint32_t*
         m.node = NONE;
         const uint32_t left = __float_as_uint(q0.w), right = __float_as_uint(q1.w);
         const uint32_t cls = node_class<COUNT>(dextra(right));
-        bool pass = true;
-        if (cls != BVH_CLASS_NO_BOX) {
-            if (COUNT) cnt.box_tests++;
-            pass = node_box_pass(sc, m, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), cls);
-        }
+        // The test is evaluated for every node, boxless ones included (their result is not used): were it conditional on
+        // the class, the compiler would fetch the class words first and the boxes after them, two round trips per move.
+        if (COUNT && cls != BVH_CLASS_NO_BOX) cnt.box_tests++;
+        const bool pass = node_box_pass(sc, m, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), cls) || cls == BVH_CLASS_NO_BOX;
         if (pass) node_descend(sc, m, idx, left, right, cls, stk, stride);
     }
 }
@@ -595,6 +599,7 @@ __device__ __forceinline__ void trav_leaf_simple(const DevScene& sc, Trav& m, Co
         if (tag == RR_TAG_RECT) rp = sc.rect, roff = 2 * idx;
         if (tag == RR_TAG_CUBOID) rp = sc.cuboid, roff = 2 * idx;
         const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
+        records_arrived(q0, q1, q2);
         m.node = NONE;
         if (tag == RR_TAG_SPHERE) {
             if (COUNT) cnt.sphere_tests++;
@@ -665,6 +670,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
         if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere;
         if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
         const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
+        records_arrived(q0, q1, q2);
         m.node = NONE;
         if (tag == RR_TAG_SPHERE) {
             if (COUNT) cnt.sphere_tests++;
@@ -1221,15 +1227,16 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             if (rejoin) park_load(pa, slot, s, m);
             const uint32_t root = uni(op.ref), ridx = didx(root);
             const uint32_t cls = node_class<COUNT>((uni(op.code) >> 8) & 3u);  // the root has a box (or the op would not be this one)
+            // the root's child words: scalar loads that are under way while the box test is made
+            const RR_CONST_AS uint32_t* rw = (const RR_CONST_AS uint32_t*)(sc.bvh) + 8u * ridx;
+            const uint32_t left = rw[3], right = rw[7];
             bool enter = false;
             if (act && s.live) {
                 if (COUNT) cnt.box_tests++;
                 enter = node_box_pass(sc, m, mk3(op.f0, op.f1, op.f2), mk3(op.f3, op.f4, op.f5), cls);
             }
-            if (__any(enter)) {
-                const uint32_t left = __float_as_uint(sc.bvh[2 * ridx].w), right = __float_as_uint(sc.bvh[2 * ridx + 1].w);
-                if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
-            }
+            asm volatile("" ::"s"(left), "s"(right));
+            if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
             const bool in = enter || rejoin;
             uint32_t steps = 0;
             for (;;) {
@@ -1638,14 +1645,10 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
         out.terminal = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
         return false;
     }
-    // which records need u,v: only image textures read them
-    HitRec rec;
-    {
-        // material id is needed before reconstruct can know about uv, so reconstruct asks for
-        // uv whenever the scene has images at all
-        rec = reconstruct_hit(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
-    }
+    // The material record is fetched first, so that it travels while the hit record is rebuilt.  Only image textures read
+    // u, v; the material is not known when reconstruct_hit asks, so it forms them whenever the scene has images at all.
     const DevMaterial m = sc.k->materials[meta.mat];
+    const HitRec rec = reconstruct_hit(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
     f3 attenuation;
     const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
