@@ -1407,6 +1407,12 @@ __device__ __forceinline__ HitMeta hit_meta(const DevScene& sc, uint32_t ref) {
 // winning (t, primitive): evaluate the primitive in its own space, then walk the
 // enclosing instances outwards applying their hit transforms.  Everything fetched here is
 // addressed by (ref, meta) alone, so the loads go out together.
+// EAGER_CHAIN: the first two instance records of the chain are fetched whatever the primitive's depth, together with the
+// primitive's words (the table is never empty; a primitive outside every instance reads the first entry's words without using
+// them).  Fetched on condition they arrive word by word in eight branches, after the depth is known; fetched eagerly they
+// cost eight registers, which the kernels of scenes with BVH subtrees do not have (measured: Cornell box +1.1 %, final_scene
+// -0.6 %, Suzanne -1.4 %), so those keep the conditional form.
+template <bool EAGER_CHAIN = false>
 __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta,
                                                   bool want_uv) {
     HitRec h;
@@ -1431,7 +1437,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     const uint32_t depth = owner_depth(owner);
     const float4* chain = sc.chain_rec + owner_inst(owner) * MAX_CHAIN;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 c0 = depth > 0 ? chain[0] : zero4, c1 = depth > 1 ? chain[1] : zero4;
+    const float4 c0 = (EAGER_CHAIN || depth > 0) ? chain[0] : zero4, c1 = (EAGER_CHAIN || depth > 1) ? chain[1] : zero4;
     f3 o = wo, d = wd;
     if (depth > 0) inst_apply_ray(c0, o, d);
     const f3 d1 = d;
@@ -1631,28 +1637,30 @@ __device__ __forceinline__ float light_pdf_value(const DevScene& sc, f3 origin, 
 }
 
 // One ray_color call (render.rs:15-41) minus the recursion.  Returns true when the
-// path goes on with ray (o, d) and its throughput multiplied by `weight`; returns
-// false when it ends with radiance `terminal` (background, emitted light, or the
-// emitted colour of a surface that does not scatter).
+// path goes on with ray (o, d) and its throughput multiplied by `value`; returns
+// false when it ends with radiance `value` (background, emitted light, or the
+// emitted colour of a surface that does not scatter).  One field for both on purpose: with two, the
+// compiler merged the stores of the different exits into one store through a selected address, which kept
+// the whole struct in scratch memory (three stores and three loads per bounce, and a wait for them).
 struct Bounce {
     f3 o, d;
-    f3 weight;
-    f3 terminal;
+    f3 value;
 };
+template <bool EAGER_CHAIN = false>
 __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta, Rng& g,
                                       Bounce& out) {
     if (ref == NONE) {
-        out.terminal = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
+        out.value = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
         return false;
     }
     // The material record is fetched first, so that it travels while the hit record is rebuilt.  Only image textures read
     // u, v; the material is not known when reconstruct_hit asks, so it forms them whenever the scene has images at all.
     const DevMaterial m = sc.k->materials[meta.mat];
-    const HitRec rec = reconstruct_hit(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
+    const HitRec rec = reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
     f3 attenuation;
     const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
-        out.terminal = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+        out.value = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
         return false;
     }
     // scatter (material.rs:85-169).  ray_color throws the scattered direction away (render.rs:32), so
@@ -1666,7 +1674,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
         const f3 sd = reflected + random_in_unit_sphere(g) * m.param;
         attenuation = own;
         if (!(dot3(sd, rec.n) > 0.0f)) {
-            out.terminal = mk3(0.0f, 0.0f, 0.0f);
+            out.value = mk3(0.0f, 0.0f, 0.0f);
             return false;
         }
     } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: always scatters, attenuation 1
@@ -1703,7 +1711,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     }
     out.o = rec.p;
     out.d = dir;
-    out.weight = (attenuation * sp) / pdf_val;  // render.rs:34, applied front to back
+    out.value = (attenuation * sp) / pdf_val;  // render.rs:34, applied front to back
     return true;
 }
 

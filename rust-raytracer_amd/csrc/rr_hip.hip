@@ -164,18 +164,18 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
             Bounce b;
 #ifdef RR_ABLATE_SHADE
             go_on = false;
-            b.terminal = mk3(t, __uint_as_float(ref), g.random());
+            b.value = mk3(t, __uint_as_float(ref), g.random());
 #else
             go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
 #endif
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
-                thr = thr * b.weight;
+                thr = thr * b.value;
                 depth_left -= 1;
                 bounce += 1;
             } else {
-                terminal = b.terminal;
+                terminal = b.value;
             }
         }
         if (path_active && !go_on) {
@@ -1212,7 +1212,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         return p.kind == RR_INST_TRANSLATE ? make_float4(u2f(p.kind), p.v[0], p.v[1], p.v[2]) : make_float4(u2f(p.kind), p.v[0], p.v[1], 0.f);
     };
     std::vector<float4> inst(static_cast<size_t>(s->n_instances) * 2);
-    std::vector<float4> chain_rec(static_cast<size_t>(s->n_instances) * MAX_CHAIN, make_float4(0.f, 0.f, 0.f, 0.f));
+    // (never empty: reconstruct_hit<true> reads the first two words of a chain whatever the primitive's depth)
+    std::vector<float4> chain_rec(static_cast<size_t>(std::max(s->n_instances, 1u)) * MAX_CHAIN, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < s->n_instances; ++i) {
         inst[2 * i] = inst_record(i);
         inst[2 * i + 1] = make_float4(u2f(to_dref(s->instances[i].child)), u2f(wk.inst_depth[i]), 0.f, 0.f);

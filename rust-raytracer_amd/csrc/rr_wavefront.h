@@ -217,16 +217,16 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
         bool go_on = false;
         if (run && !parked) {
             Bounce b;
-            go_on = shade(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
+            go_on = shade<!PARK>(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
-                thr = thr * b.weight;
+                thr = thr * b.value;
                 depth_left -= 1;
                 bounce += 1;
                 if (PARK) draws = 0;
             } else {
-                terminal = b.terminal;
+                terminal = b.value;
             }
         }
         if (path_active && !go_on && !parked) {
@@ -405,21 +405,21 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
                 Bounce b;
 #ifdef RR_ABLATE_WF_SHADE  // timing-only builds: wrong images, price the sections of the kernel
                 keep = h.y != NONE && (p & 3u) != 0u;
-                b.o = ro + rd * __uint_as_float(h.x), b.d = rd, b.weight = mk3(0.5f, 0.5f, g.random()), b.terminal = b.weight;
+                b.o = ro + rd * __uint_as_float(h.x), b.d = rd, b.value = mk3(0.5f, 0.5f, g.random());
 #if RR_ABLATE_WF_SHADE >= 2
                 if (h.y != NONE) {
                     const HitRec rec = reconstruct_hit(sc, ro, rd, time, __uint_as_float(h.x), h.y, HitMeta{h.z, h.w}, false);
                     b.o = rec.p, b.d = rec.n;
 #if RR_ABLATE_WF_SHADE >= 3
                     const DevMaterial mm = sc.k->materials[h.z];
-                    b.weight = mk3(mm.r, mm.g, mm.b);
+                    b.value = mk3(mm.r, mm.g, mm.b);
 #endif
 #if RR_ABLATE_WF_SHADE >= 4
                     const f3 cd = random_cosine_direction(g);
                     b.d = b.d + cd;
 #endif
 #if RR_ABLATE_WF_SHADE >= 5
-                    b.weight.x = light_pdf_value(sc, rec.p, b.d);
+                    b.value.x = light_pdf_value(sc, rec.p, b.d);
 #endif
                 }
 #endif
@@ -427,13 +427,13 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
                 keep = shade(sc, ro, rd, time, __uint_as_float(h.x), h.y, HitMeta{h.z, h.w}, g, b);
 #endif
                 if (keep) {
-                    thr = thr * b.weight;
+                    thr = thr * b.value;
                     depth_left -= 1;
                     st.ray_o[p] = make_float4(b.o.x, b.o.y, b.o.z, time);
                     st.ray_d[p] = make_float4(b.d.x, b.d.y, b.d.z, __uint_as_float(depth_left));
                     st.thr[p] = make_float4(thr.x, thr.y, thr.z, 0.f);
                 } else {
-                    terminal = b.terminal;
+                    terminal = b.value;
                 }
             }
             if (!keep) {
@@ -544,11 +544,11 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
-                thr = thr * b.weight;
+                thr = thr * b.value;
                 depth_left -= 1;
                 draws = 0;
             } else {
-                terminal = b.terminal;
+                terminal = b.value;
             }
         }
         if (have && !go_on && !parked) {
