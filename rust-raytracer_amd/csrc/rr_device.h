@@ -950,13 +950,55 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
 // w2..w7 = six f32 operands.
 constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
                    OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
-                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16;
+                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16, OP_MED_SPHERE = 17;
 constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
 
 struct Op {
     uint32_t code, ref;
     float f0, f1, f2, f3, f4, f5;
 };
+
+// OP_MED_SPHERE: a constant medium whose boundary is a bare sphere (collider.rs:435-475 over collider.rs:278-292), in one op:
+// centre in f0..f2, radius in f3, -1/density in f4, ref = the medium.  The two boundary probes solve the same quadratic for the
+// same ray and differ only in the range a root must lie in, so the discriminant, its square root and the two quotients are
+// formed once; every value is the one the separate ops (OP_MED_BEGIN, OP_SPHERE, OP_MED_MID, OP_SPHERE, OP_MED_END) form.
+template <int COUNT>
+__device__ __forceinline__ void medium_in_sphere(const Op& op, f3 o, f3 d, float tmin, float& tmax, uint32_t& cur, bool live, Rng& rng,
+                                                 Counts& cnt) {
+    if (COUNT && live) cnt.inst_visits++, cnt.sphere_tests++;
+    const f3 oc = o - mk3(op.f0, op.f1, op.f2);
+    const float a = len2(d);
+    const float half_b = dot3(oc, d);
+    const float cc = len2(oc) - op.f3 * op.f3;
+    const float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return;  // the first probe misses (a NaN discriminant goes on, as in test_sphere)
+    const float sq = sqrtf(disc);
+    const float ra = (-half_b - sq) / a, rb = (-half_b + sq) / a;
+    float t1 = ra;  // first probe over (f32::MIN, f32::MAX), collider.rs:437
+    if (t1 < -kF32Max || kF32Max < t1) {
+        t1 = rb;
+        if (t1 < -kF32Max || kF32Max < t1) return;
+    }
+    if (!live) return;
+    if (COUNT) cnt.sphere_tests++;
+    const float lo = t1 + 0.0001f;  // second probe over (t1 + 0.0001, f32::MAX), collider.rs:443
+    float t2 = ra;
+    if (t2 < lo || kF32Max < t2) {
+        t2 = rb;
+        if (t2 < lo || kF32Max < t2) return;
+    }
+    if (t1 < tmin) t1 = tmin;  // collider.rs:448-474
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return;  // (a NaN bound goes on)
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_length = len3(d);
+    const float dist_inside = (t2 - t1) * ray_length;
+    const float hit_dist = op.f4 * log10f(rng.random());
+    if (!(hit_dist > dist_inside)) {
+        tmax = t1 + hit_dist / ray_length;
+        cur = op.ref;
+    }
+}
 
 // SceneColliders::intersect (collider.rs:751-772) for the world ray (wo, wd).  (tmax, cur) carry
 // the closest hit so far through the fold; `live` is false only for lanes whose first medium
@@ -1043,6 +1085,8 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
 #ifndef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             if (live) machine<COUNT>(sc, uni(op.ref), wo, wd, o, d, time, tmin, tmax, cur, rng, stk, stride, cnt);
 #endif
+        } else if (code == OP_MED_SPHERE) {
+            medium_in_sphere<COUNT>(op, o, d, tmin, tmax, cur, live, rng, cnt);
         } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
             if (COUNT && live) cnt.inst_visits++;
             m_tmin = tmin, m_tmax = tmax, m_cur = cur;
@@ -1334,6 +1378,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 }
             } else if (code == OP_LEAF_REF) {  // triangles and moving spheres at program level: record by scalar load
                 if (s.live) eval_leaf<COUNT>(sc, uni(op.ref), s.o, s.d, time, s.tmin, s.tmax, s.cur, pcnt);
+            } else if (code == OP_MED_SPHERE) {
+                medium_in_sphere<COUNT>(op, s.o, s.d, s.tmin, s.tmax, s.cur, s.live, rng, pcnt);
             } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
                 if (COUNT && s.live) pcnt.inst_visits++;
                 s.m_tmin = s.tmin, s.m_tmax = s.tmax, s.m_cur = s.cur;

@@ -690,6 +690,11 @@ struct ProgramBuilder {
                     ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
                     break;
                 }
+                if (RR_REF_TAG(s.media[idx].boundary) == RR_TAG_SPHERE) {  // both probes of a bare sphere in one op
+                    const rr_sphere& p = s.spheres[RR_REF_INDEX(s.media[idx].boundary)];
+                    ops.push_back(make(OP_MED_SPHERE, dref(tag, idx), p.center[0], p.center[1], p.center[2], p.radius, s.media[idx].neg_inv_density));
+                    break;
+                }
                 in_medium = true;
                 ops.push_back(make(OP_MED_BEGIN));
                 emit(s.media[idx].boundary);
@@ -1320,7 +1325,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         const bool subtree = code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE;
         ctx->has_subtrees |= subtree;
         ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
-        top_ops += !subtree && code != OP_END && code != OP_RESET;
+        top_ops += code == OP_MED_SPHERE ? 5u : (!subtree && code != OP_END && code != OP_RESET);  // (the fused op stands for five)
     }
     // Scenes with BVH subtrees: when nearly everything is inside the subtrees, the bounce kernels of the wavefront
     // pipeline (pure traversal at twice the occupancy) are the faster way through the camera rays; when the scene
