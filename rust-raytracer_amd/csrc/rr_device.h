@@ -107,6 +107,7 @@ struct DevScene {  // kernel argument
     const uint2* list;          // (first child, n children)
     const uint32_t* child_refs;
     const RR_CONST_AS uint4* prog;  // scene program, 2 uint4 (one 32-byte op) per entry, terminated by OP_END
+    uint32_t n_ops;                 // ops before the terminating OP_ENDs
     float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
     uint32_t intended;              // RR_SEMANTICS_INTENDED: the labelled alternative semantics (see include/rr_hip.h), 0 by default
     const RR_CONST_AS DevConst* k;
@@ -950,13 +951,44 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
 // w2..w7 = six f32 operands.
 constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
                    OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
-                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16, OP_MED_SPHERE = 17;
+                   OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16, OP_MED_SPHERE = 17, OP_XFORM = 18;
 constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
+// OP_XFORM: a run of OP_RESET, OP_TRANSLATE, OP_ROT_* in that order (each at most once) as one op: an op of three
+// instructions costs a wave as much to fetch and dispatch as one of a hundred.  Translation in f0..f2, (sin, cos) in f3, f4.
+constexpr uint32_t OPX_RESET = 1u << 8, OPX_TRANSLATE = 1u << 9, OPX_COUNT_TRANSLATE = 1u << 10, OPX_COUNT_ROT = 1u << 11,
+                   OPX_ROT_SHIFT = 12;  // two bits: 0 no rotation, 1 + axis otherwise
 
 struct Op {
     uint32_t code, ref;
     float f0, f1, f2, f3, f4, f5;
 };
+
+// The transforms of OP_XFORM on the ray (o, d) (collider.rs:481, 499-509); returns the instance visits it counts.
+__device__ __forceinline__ uint32_t xform_op(const Op& op, uint32_t flags, f3 wo, f3 wd, f3& o, f3& d) {
+    uint32_t visits = 0;
+    if (flags & OPX_RESET) o = wo, d = wd;
+    if (flags & OPX_TRANSLATE) {
+        visits += (flags & OPX_COUNT_TRANSLATE) ? 1u : 0u;
+        o = o - mk3(op.f0, op.f1, op.f2);
+    }
+    const uint32_t rot = (flags >> OPX_ROT_SHIFT) & 3u;
+    if (rot != 0u) {
+        visits += (flags & OPX_COUNT_ROT) ? 1u : 0u;
+        const float sn = op.f3, c = op.f4;
+        const f3 po = o, pd = d;
+        if (rot == 2u) {  // about y
+            o.x = c * po.x - sn * po.z, o.z = sn * po.x + c * po.z;
+            d.x = c * pd.x - sn * pd.z, d.z = sn * pd.x + c * pd.z;
+        } else if (rot == 1u) {  // about x
+            o.y = c * po.y - sn * po.z, o.z = sn * po.y + c * po.z;
+            d.y = c * pd.y - sn * pd.z, d.z = sn * pd.y + c * pd.z;
+        } else {  // about z
+            o.x = c * po.x - sn * po.y, o.y = sn * po.x + c * po.y;
+            d.x = c * pd.x - sn * pd.y, d.y = sn * pd.x + c * pd.y;
+        }
+    }
+    return visits;
+}
 
 // OP_MED_SPHERE: a constant medium whose boundary is a bare sphere (collider.rs:435-475 over collider.rs:278-292), in one op:
 // centre in f0..f2, radius in f3, -1/density in f4, ref = the medium.  The two boundary probes solve the same quadratic for the
@@ -1018,14 +1050,15 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
     const RR_CONST_AS Op* prog = reinterpret_cast<const RR_CONST_AS Op*>(sc.prog);
     Op next = prog[0];
     asm volatile("" ::"s"(next.code));  // the first op has arrived before the loop: inside it only the fetch of the op after the current one is in flight
-    uint32_t pc = 0;  // wave-uniform by construction; uni() keeps it in an SGPR
-    for (;;) {
+    // A counted loop over a moving pointer: the scalar unit is shared by the sixteen waves of a CU, and every scalar instruction
+    // of an op's fetch and dispatch (index arithmetic, a test for OP_END with its exit bookkeeping) is paid sixteen times.
+    const uint32_t n_ops = uni(sc.n_ops);
+    for (uint32_t pc = 0; pc != n_ops; ++pc) {
         // the op after this one is fetched while this one executes (the program ends in two OP_ENDs)
         const Op op = next;
-        pc = uni(pc + 1);
-        next = prog[pc];
+        ++prog;
+        next = *prog;
         const uint32_t code = uni(op.code) & 0xFFu;
-        if (code == OP_END) break;
         if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
             if (COUNT && live) cnt.rect_tests++;
             float t;
@@ -1050,6 +1083,9 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
             if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f3, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 4;
             if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f0, o, d, tmin, tmax, t)) tmax = live ? t : tmax, side = 5;
             if (live && side != NONE) cur = op.ref + side;
+        } else if (code == OP_XFORM) {
+            const uint32_t visits = xform_op(op, uni(op.code), wo, wd, o, d);
+            if (COUNT && live) cnt.inst_visits += visits;
         } else if (code == OP_RESET) {
             o = wo;
             d = wd;
@@ -1251,7 +1287,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         if (!(n < park_below && steps >= min_steps)) return false;
         return static_cast<uint32_t>(__popcll(__ballot(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
-    for (;;) {
+    for (;;) {  // (the counted loop of traverse measured slower here: -1.5 % final_scene, -4.6 % Suzanne; this kernel has no scalar registers to spare)
         const Op op = next;
         const uint32_t this_pc = pc;
         pc = uni(pc + 1);
@@ -1346,6 +1382,9 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f3, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 4;
                 if (test_rect_axis<RR_RECT_YZ>(op.f1, op.f4, op.f2, op.f5, op.f0, s.o, s.d, s.tmin, s.tmax, t)) s.tmax = live ? t : s.tmax, side = 5;
                 if (live && side != NONE) s.cur = op.ref + side;
+            } else if (code == OP_XFORM) {
+                const uint32_t visits = xform_op(op, uni(op.code), wo, wd, s.o, s.d);
+                if (COUNT && s.live) pcnt.inst_visits += visits;
             } else if (code == OP_RESET) {
                 s.o = wo;
                 s.d = wd;

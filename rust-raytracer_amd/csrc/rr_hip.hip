@@ -639,6 +639,34 @@ struct ProgramBuilder {
         for (size_t k = common; k < chain.size(); ++k) xform(chain[k], false);
         space = chain;
     }
+    // Runs of OP_RESET, OP_TRANSLATE, OP_ROT_* (in that order, each at most once) become one OP_XFORM each.
+    void fuse_transforms() {
+        std::vector<Op> out;
+        for (size_t i = 0; i < ops.size();) {
+            auto code_at = [&](size_t k) { return k < ops.size() ? (ops[k].code & 0xFFu) : OP_END; };
+            auto is_rot = [&](uint32_t c) { return c >= OP_ROT_X && c <= OP_ROT_Z; };
+            const uint32_t c0 = code_at(i);
+            if (c0 != OP_RESET && c0 != OP_TRANSLATE && !is_rot(c0)) {
+                out.push_back(ops[i++]);
+                continue;
+            }
+            Op x = make(OP_XFORM);
+            size_t n = 0;
+            if (code_at(i) == OP_RESET) x.code |= OPX_RESET, ++i, ++n;
+            if (code_at(i) == OP_TRANSLATE) {
+                x.code |= OPX_TRANSLATE | ((ops[i].code & OPF_COUNT_VISIT) ? OPX_COUNT_TRANSLATE : 0u);
+                x.f0 = ops[i].f0, x.f1 = ops[i].f1, x.f2 = ops[i].f2;
+                ++i, ++n;
+            }
+            if (is_rot(code_at(i))) {
+                x.code |= ((code_at(i) - OP_ROT_X + 1u) << OPX_ROT_SHIFT) | ((ops[i].code & OPF_COUNT_VISIT) ? OPX_COUNT_ROT : 0u);
+                x.f3 = ops[i].f0, x.f4 = ops[i].f1;
+                ++i, ++n;
+            }
+            out.push_back(x);
+        }
+        ops.swap(out);
+    }
     void rect_op(uint32_t ri) {
         const rr_rect& r = s.rects[ri];
         const uint32_t code = r.axis == RR_RECT_XY ? OP_RECT_XY : (r.axis == RR_RECT_XZ ? OP_RECT_XZ : OP_RECT_YZ);
@@ -1269,8 +1297,21 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
     ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false};
     pb.emit(s->root);
+    pb.fuse_transforms();
+    if (const char* pad = std::getenv("RR_PAD_OPS"))  // for measurements: ops that do nothing, to price an op's way through the interpreter
+        for (int i = 0; i < std::atoi(pad); ++i) pb.ops.push_back(ProgramBuilder::make(OP_XFORM));
+    const uint32_t n_ops = static_cast<uint32_t>(pb.ops.size());
     pb.ops.push_back(ProgramBuilder::make(OP_END));
     pb.ops.push_back(ProgramBuilder::make(OP_END));  // the interpreter prefetches one op past the one it runs
+    if (std::getenv("RR_DUMP_PROGRAM")) {  // for whoever tunes the program: its ops, one per line, to stderr
+        static const char* const names[] = {"END", "RESET", "TRANSLATE", "ROT_X", "ROT_Y", "ROT_Z", "RECT_XY", "RECT_XZ", "RECT_YZ", "SPHERE", "LEAF_REF",
+                                            "SUBTREE", "MED_BEGIN", "MED_MID", "MED_END", "CUBOID", "SUBTREE_SIMPLE", "MED_SPHERE", "XFORM"};
+        for (size_t i = 0; i < pb.ops.size(); ++i) {
+            const Op& o = pb.ops[i];
+            std::fprintf(stderr, "op %3zu %-14s flags %02x ref %08x  %g %g %g %g %g %g\n", i, names[std::min<uint32_t>(o.code & 0xFFu, 18u)], o.code >> 8, o.ref,
+                         o.f0, o.f1, o.f2, o.f3, o.f4, o.f5);
+        }
+    }
     static_assert(sizeof(Op) == 32, "one op is two 16-byte words");
     std::vector<uint4> prog(pb.ops.size() * 2);
     std::memcpy(prog.data(), pb.ops.data(), pb.ops.size() * sizeof(Op));
@@ -1297,6 +1338,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         return rc;
     }
     d.prog = (decltype(d.prog))prog_dev;  // C-style cast: the member is address-space qualified in the device pass
+    d.n_ops = n_ops;
     k.light_is_xzrect = s->light.is_xzrect ? 1u : 0u;
     k.light_x0 = s->light.x0;
     k.light_x1 = s->light.x1;
@@ -1325,7 +1367,10 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         const bool subtree = code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE;
         ctx->has_subtrees |= subtree;
         ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
-        top_ops += code == OP_MED_SPHERE ? 5u : (!subtree && code != OP_END && code != OP_RESET);  // (the fused op stands for five)
+        // (the fused ops count as the ops they stand for)
+        if (code == OP_MED_SPHERE) top_ops += 5u;
+        else if (code == OP_XFORM) top_ops += ((op.code & OPX_TRANSLATE) ? 1u : 0u) + (((op.code >> OPX_ROT_SHIFT) & 3u) ? 1u : 0u);
+        else top_ops += !subtree && code != OP_END && code != OP_RESET;
     }
     // Scenes with BVH subtrees: when nearly everything is inside the subtrees, the bounce kernels of the wavefront
     // pipeline (pure traversal at twice the occupancy) are the faster way through the camera rays; when the scene
