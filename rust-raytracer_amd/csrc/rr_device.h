@@ -496,18 +496,17 @@ __device__ __forceinline__ bool node_box_pass(const DevScene& sc, const Trav& m,
     // `t1 > t_min ? t1 : t_min` and `t0 < t_max ? t0 : t_max` (a NaN never replaces a bound:
     // fmaxf/fminf keep the other operand too), and the node is rejected once t_max <= t_min.
     // Bounds only tighten, so testing once after the third axis rejects the same rays.
-    const float lo = fmaxf(fmaxf(m.tmin, nx ? ex : m.tmin), fmaxf(ny ? ey : m.tmin, nz ? ez : m.tmin));
-    const float hi = fminf(fminf(m.tmax, nx ? fx : m.tmax), fminf(ny ? fy : m.tmax, nz ? fz : m.tmax));
+    // Under the labelled intended semantics every axis clips, and the box test itself is then the cull.  (The flags
+    // below do not change while a ray descends: the compiler forms them once per visit, where a branch on the
+    // semantics would cost scalar instructions at every node.)
+    const bool all_axes = sc.intended != 0u;
+    const bool cx = nx || all_axes, cy = ny || all_axes, cz = nz || all_axes;
+    const float lo = fmaxf(fmaxf(m.tmin, cx ? ex : m.tmin), fmaxf(cy ? ey : m.tmin, cz ? ez : m.tmin));
+    const float hi = fminf(fminf(m.tmax, cx ? fx : m.tmax), fminf(cy ? fy : m.tmax, cz ? fz : m.tmax));
     // (A bound that is NaN on entry — the t of a degenerate hit — stays NaN in the reference and
     // fails no comparison, where fmaxf/fminf would drop it.)
-    if (sc.intended) {
-        // the labelled intended semantics: every axis clips, and the box test itself is then the cull
-        const float lo3 = fmaxf(fmaxf(m.tmin, ex), fmaxf(ey, ez));
-        const float hi3 = fminf(fminf(m.tmax, fx), fminf(fy, fz));
-        return !(hi3 <= lo3) || __builtin_isunordered(m.tmin, m.tmax);
-    }
     bool pass = !(hi <= lo) || __builtin_isunordered(m.tmin, m.tmax);
-    if (cls >= BVH_CLASS_CULL_RANGE && m.cull) {
+    if (cls >= BVH_CLASS_CULL_RANGE && m.cull && !all_axes) {
         // All three slabs of the box grown by the margin, against the segment no accepted hit can lie
         // outside of.  The margin grows with the squared distance from the ray origin to the farthest
         // point of the box, as the rounding errors of the intersectors below do.
@@ -529,21 +528,10 @@ __device__ __forceinline__ void node_descend(const DevScene& sc, Trav& m, uint32
                                              uint32_t stride) {
     const uint32_t l = left & REF_MASK, r = right & REF_MASK;
     const bool dirpos = comp(m.d, dextra(left)) >= 0.0f;
-    if (sc.intended) {
-        // the labelled intended semantics (src/bvh.rs:19-44): the other child follows the first after a hit and after a miss
-        // alike; a span-1 node's second visit is only left out where it cannot draw random numbers
-        if (cls >= BVH_CLASS_CULL_RANGE && l == r) {
-            m.node = l;
-        } else {
-            stk[m.sp * stride] = (dirpos ? r : l) | (m.hitf ? FW_FLAG : 0u);
-            m.sp += 1;
-            m.hitf = false;
-            m.node = dirpos ? l : r;
-        }
-        return;
-    }
     // In the culling classes evaluating the same child twice over the same or a smaller
     // range cannot change the outcome.  The reference-order counting build evaluates everything.
+    // Under the labelled intended semantics (src/bvh.rs:19-44) the other child follows the first after a hit and after a
+    // miss alike, and a span-1 node's second visit is only left out where it cannot draw random numbers (its classes say so).
     const bool pure = cls >= BVH_CLASS_CULL_RANGE;
     if (pure && l == r) {
         m.node = l;  // span-1 node: the second visit repeats the first
@@ -551,6 +539,8 @@ __device__ __forceinline__ void node_descend(const DevScene& sc, Trav& m, uint32
         uint32_t fw;
         if (!dirpos)
             fw = l;  // right first; left follows after a hit and after a miss alike
+        else if (sc.intended != 0u)
+            fw = r;
         else if (pure)
             fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
         else
@@ -1328,7 +1318,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (going) trav_node<COUNT>(sc, m, stk, stride, cnt);
                 const bool at_leaf = going && trav_at_leaf(m);
                 const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
-                if (leaf_wait == 0u || n_leaf * leaf_wait >= n || !__any(going && !at_leaf)) {
+                // (when every lane that descends is at a leaf, n_leaf == n, the test holds whatever the fraction)
+                if (leaf_wait == 0u || n_leaf * leaf_wait >= n) {
                     if (at_leaf) trav_leaf_simple<COUNT>(sc, m, cnt);
                 }
                 if (going) trav_pop_simple(sc, m, stk, stride);
