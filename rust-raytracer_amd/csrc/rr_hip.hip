@@ -613,6 +613,7 @@ struct ProgramBuilder {
     std::vector<uint32_t> chain;  // instances enclosing the node being emitted, outermost first
     std::vector<uint32_t> space;  // instances the ops emitted so far have applied to the ray
     bool in_medium = false;
+    bool fuse = true;  // emit the fused ops (OP_MED_SPHERE, OP_XFORM); off under RR_NO_FUSE, for the test that compares the two forms
 
     static Op make(uint32_t code, uint32_t ref = NONE, float f0 = 0, float f1 = 0, float f2 = 0, float f3 = 0, float f4 = 0,
                    float f5 = 0) {
@@ -718,7 +719,7 @@ struct ProgramBuilder {
                     ops.push_back(make(OP_SUBTREE, dref(tag, idx)));
                     break;
                 }
-                if (RR_REF_TAG(s.media[idx].boundary) == RR_TAG_SPHERE) {  // both probes of a bare sphere in one op
+                if (fuse && RR_REF_TAG(s.media[idx].boundary) == RR_TAG_SPHERE) {  // both probes of a bare sphere in one op
                     const rr_sphere& p = s.spheres[RR_REF_INDEX(s.media[idx].boundary)];
                     ops.push_back(make(OP_MED_SPHERE, dref(tag, idx), p.center[0], p.center[1], p.center[2], p.radius, s.media[idx].neg_inv_density));
                     break;
@@ -1295,9 +1296,9 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevImage> images(s->n_images);
     for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
-    ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false};
+    ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false, std::getenv("RR_NO_FUSE") == nullptr};
     pb.emit(s->root);
-    pb.fuse_transforms();
+    if (pb.fuse) pb.fuse_transforms();
     if (const char* pad = std::getenv("RR_PAD_OPS"))  // for measurements: ops that do nothing, to price an op's way through the interpreter
         for (int i = 0; i < std::atoi(pad); ++i) pb.ops.push_back(ProgramBuilder::make(OP_XFORM));
     const uint32_t n_ops = static_cast<uint32_t>(pb.ops.size());

@@ -177,6 +177,11 @@ def _random_scene(seed):
     b.add(b.collider_list([b.sphere(c, 3.0, mat()), b.collider_list([b.yzrect(c[1], c[1] + 5, c[2], c[2] + 6, float(c[0]) - 8, mat()),
                                                                        group(3, 2.0), b.sphere(c + 7, 2.0, mat())]),
                            b.cuboid(c - 9, c - 5, mat())]))
+    # media bounded by a bare sphere (one fused op of the scene program): around much of the scene, small, inside instances
+    b.add(b.constant_medium(b.sphere(rng.uniform(-5, 5, 3), 70.0, mats[0]), 0.004, (0.8, 0.9, 1.0)))
+    b.add(b.constant_medium(b.sphere(rng.uniform(-30, 30, 3), float(rng.uniform(3, 9)), mats[0]), 0.2, (0.3, 0.2, 0.1)))
+    b.add(b.instance_translation(b.instance_rotation(b.constant_medium(b.sphere((1, 2, 3), 6.0, mats[0]), 0.3, (0.5, 0.5, 0.5)), 2, 25.0),
+                                 rng.uniform(-25, 25, 3)))
     b.set_lights(b.xzrect(-5, 5, -5, 5, 60.0, mats[3]))
     b.set_camera((0, 20, -120), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
     b.set_background((0.5, 0.6, 0.9))
@@ -215,6 +220,34 @@ def test_renders_of_random_scenes_agree_between_all_kernel_forms(gpu_ctx, seed):
     both = ~nan_got & ~nan_want
     assert both.mean() > 0.05, "too few samples without NaN to compare"
     assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.995
+
+
+@pytest.mark.parametrize("which", ["final", "cornell", "suzanne", "random 41", "random 44"])
+def test_fused_ops_of_the_scene_program_equal_the_ops_they_stand_for(gpu_ctx, monkeypatch, which):
+    """OP_MED_SPHERE (a medium bounded by a bare sphere: both probes from one discriminant) and OP_XFORM (a run of reset,
+    translate, rotate) against the same scene uploaded with one op per step (RR_NO_FUSE): same hits, same samples, same
+    counters, bit for bit."""
+    if which.startswith("random"):
+        b, flat = _random_scene(int(which.split()[1]))
+    else:
+        b, flat, _ = config_scene(which)
+    rays = _stress_rays(flat, 40_000, seed=21)
+    kw = dict(n_slices=4, max_depth=30, seed=8)
+    out = []
+    for no_fuse in (False, True):
+        if no_fuse:
+            monkeypatch.setenv("RR_NO_FUSE", "1")
+        gpu_ctx.upload(flat)
+        hits = gpu_ctx.primary_hits(rays, seed=4)
+        r = gpu_ctx.render(device.make_params(72, 56, 8, flags=abi.FLAG_COUNTERS, **kw))
+        r2 = gpu_ctx.render(device.make_params(72, 56, 8, **kw))
+        out.append((hits, r, r2))
+    monkeypatch.delenv("RR_NO_FUSE")
+    (h0, a0, b0), (h1, a1, b1) = out
+    assert np.array_equal(h0.tobytes(), h1.tobytes()) or all(np.array_equal(h0[f], h1[f], equal_nan=True) for f in h0.dtype.names)
+    assert np.array_equal(a0["slice_sums"], a1["slice_sums"], equal_nan=True) and counts(a0) == counts(a1)
+    assert np.array_equal(b0["slice_sums"], b1["slice_sums"], equal_nan=True)
+    assert np.array_equal(a0["slice_sums"], b0["slice_sums"], equal_nan=True)
 
 
 # ------------------------------------------------- the labelled intended semantics
