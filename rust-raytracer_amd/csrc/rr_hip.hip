@@ -327,6 +327,7 @@ struct rr_context {
     // and a grow-only workspace (path state, two queues, queue controls) with a pinned word through
     // which the host reads the live-path count when it has to (RR_FLAG_NO_FINISH_KERNEL)
     bool has_subtrees = false;
+    bool has_general_subtrees = false;  // OP_SUBTREE ops: subtrees the simple machine moves do not cover
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
     bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
     uint32_t root = NONE;
@@ -972,7 +973,8 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     // (a scene without BVH nodes has no visits to skip: its two counting modes are one kernel)
     const PathsKernel kernel =
         ctx->has_subtrees ? (count == COUNT_PRODUCTION  ? k_wf_paths<COUNT_PRODUCTION, true, true>
-                             : count == COUNT_REFERENCE ? k_wf_paths<COUNT_REFERENCE, true, true> : k_wf_paths<COUNT_OFF, true, true>)
+                             : count == COUNT_REFERENCE ? k_wf_paths<COUNT_REFERENCE, true, true>
+                             : ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true> : k_wf_paths<COUNT_OFF, true, true, false>)
         : ctx->prog_vector_ops ? (count ? k_wf_paths<COUNT_REFERENCE, true> : k_wf_paths<COUNT_OFF, true>)
                                : (count ? k_wf_paths<COUNT_REFERENCE, false> : k_wf_paths<COUNT_OFF, false>);
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
@@ -1361,12 +1363,14 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
     ctx->has_subtrees = false;
+    ctx->has_general_subtrees = false;
     ctx->prog_vector_ops = false;
     uint32_t top_ops = 0;  // ops of the scene program that test or transform something outside the BVH subtrees
     for (const Op& op : pb.ops) {
         const uint32_t code = op.code & 0xFFu;
         const bool subtree = code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE;
         ctx->has_subtrees |= subtree;
+        ctx->has_general_subtrees |= code == OP_SUBTREE;
         ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
         // (the fused ops count as the ops they stand for)
         if (code == OP_MED_SPHERE) top_ops += 5u;

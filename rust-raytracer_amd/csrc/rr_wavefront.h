@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-template <int COUNT, bool VEC, bool PARK = false>
+template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true>
 __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
             if (g.n & 3u) g.refill();
             const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !was_parked)));
             const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
-            traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
+            traverse_parking<COUNT, GENERAL>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
             draws = g.n;
             parked = run && park != NONE;
         } else {
