@@ -1483,6 +1483,38 @@ __device__ __forceinline__ HitMeta hit_meta(const DevScene& sc, uint32_t ref) {
     return m;
 }
 
+// hit_meta and the words of the primitive's record that reconstruct_hit needs, requested together: one wait instead of two
+// on the way from the hit to its material.
+struct HitFetch {
+    HitMeta meta;
+    float4 r0, r1;
+};
+__device__ __forceinline__ HitFetch hit_fetch(const DevScene& sc, uint32_t ref) {
+    const uint32_t tag = dtag(ref), idx = didx(ref);
+    HitFetch f;
+    f.r0 = f.r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tag == RR_TAG_SPHERE) {
+        const uint2 v = sc.k->sphere_meta[idx];
+        f.r0 = sc.sphere[idx];
+        f.meta.mat = v.x, f.meta.owner = v.y;
+    } else if (tag == RR_TAG_RECT) {
+        f.r0 = sc.rect[2 * idx];
+        f.r1 = sc.rect[2 * idx + 1];
+        f.meta.mat = __float_as_uint(f.r1.z), f.meta.owner = __float_as_uint(f.r1.w);
+    } else if (tag == RR_TAG_TRIANGLE) {
+        const uint2 v = sc.k->tri_meta[idx];
+        f.r0 = sc.tri[3 * idx + 2];
+        f.meta.mat = v.x, f.meta.owner = v.y;
+    } else if (tag == RR_TAG_MOVING_SPHERE) {
+        f.r0 = sc.msphere[3 * idx + 2];
+        f.meta.mat = __float_as_uint(f.r0.y), f.meta.owner = __float_as_uint(f.r0.z);
+    } else {  // medium
+        const uint4 v = sc.medium[idx];
+        f.meta.mat = v.z, f.meta.owner = v.w;
+    }
+    return f;
+}
+
 // Rebuild the HitRecord (material.rs:8-38) the reference would have returned for the
 // winning (t, primitive): evaluate the primitive in its own space, then walk the
 // enclosing instances outwards applying their hit transforms.  Everything fetched here is
@@ -1494,7 +1526,7 @@ __device__ __forceinline__ HitMeta hit_meta(const DevScene& sc, uint32_t ref) {
 // -0.6 %, Suzanne -1.4 %), so those keep the conditional form.
 template <bool EAGER_CHAIN = false>
 __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta,
-                                                  bool want_uv) {
+                                                  float4 r0, float4 r1, bool want_uv) {  // r0, r1: the record words hit_fetch reads
     HitRec h;
     h.t = t;
     h.u = 0.0f;
@@ -1502,17 +1534,6 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     h.mat = meta.mat;
     const uint32_t tag = dtag(ref), idx = didx(ref);
     const uint32_t owner = meta.owner;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;  // record words reused below
-    if (tag == RR_TAG_SPHERE) {
-        r0 = sc.sphere[idx];
-    } else if (tag == RR_TAG_RECT) {
-        r0 = sc.rect[2 * idx];
-        r1 = sc.rect[2 * idx + 1];
-    } else if (tag == RR_TAG_TRIANGLE) {
-        r0 = sc.tri[3 * idx + 2];
-    } else if (tag == RR_TAG_MOVING_SPHERE) {
-        r0 = sc.msphere[3 * idx + 2];
-    }
     // the ray in the primitive's space; the directions inside the two outermost instances are kept for the way back
     const uint32_t depth = owner_depth(owner);
     const float4* chain = sc.chain_rec + owner_inst(owner) * MAX_CHAIN;
@@ -1578,6 +1599,24 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     if (depth > 1) inst_apply_hit(c1, d2, h.p, h.n, h.front);
     if (depth > 0) inst_apply_hit(c0, d1, h.p, h.n, h.front);
     return h;
+}
+// The same for a caller that has the meta words already (the wavefront pipeline's hit records carry them).
+template <bool EAGER_CHAIN = false>
+__device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta,
+                                                  bool want_uv) {
+    const uint32_t tag = dtag(ref), idx = didx(ref);
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    if (tag == RR_TAG_SPHERE) {
+        r0 = sc.sphere[idx];
+    } else if (tag == RR_TAG_RECT) {
+        r0 = sc.rect[2 * idx];
+        r1 = sc.rect[2 * idx + 1];
+    } else if (tag == RR_TAG_TRIANGLE) {
+        r0 = sc.tri[3 * idx + 2];
+    } else if (tag == RR_TAG_MOVING_SPHERE) {
+        r0 = sc.msphere[3 * idx + 2];
+    }
+    return reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, r0, r1, want_uv);
 }
 
 // ------------------------------------------------------- perlin / textures
@@ -1726,9 +1765,10 @@ struct Bounce {
     f3 o, d;
     f3 value;
 };
-template <bool EAGER_CHAIN = false>
+template <bool EAGER_CHAIN = false, bool FETCHED = false>
 __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float time, float t, uint32_t ref, HitMeta meta, Rng& g,
-                                      Bounce& out) {
+                                      Bounce& out, float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f)) {
+    // FETCHED: r0, r1 are the primitive's record words, read with the meta words (hit_fetch)
     if (ref == NONE) {
         out.value = mk3(sc.k->background[0], sc.k->background[1], sc.k->background[2]);
         return false;
@@ -1736,7 +1776,8 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     // The material record is fetched first, so that it travels while the hit record is rebuilt.  Only image textures read
     // u, v; the material is not known when reconstruct_hit asks, so it forms them whenever the scene has images at all.
     const DevMaterial m = sc.k->materials[meta.mat];
-    const HitRec rec = reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
+    const HitRec rec = FETCHED ? reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, r0, r1, sc.k->images != nullptr)
+                               : reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
     f3 attenuation;
     const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181

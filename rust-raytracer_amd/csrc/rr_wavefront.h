@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
         bool go_on = false;
         if (run && !parked) {
             Bounce b;
-            go_on = shade<!PARK>(sc, ro, rd, time, t, ref, ref == NONE ? HitMeta{0u, 0u} : hit_meta(sc, ref), g, b);
+            HitFetch hf{};
+            if (ref != NONE) hf = hit_fetch(sc, ref);
+            go_on = shade<!PARK, true>(sc, ro, rd, time, t, ref, hf.meta, g, b, hf.r0, hf.r1);
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
