@@ -1730,8 +1730,10 @@ __device__ __forceinline__ f3 random_cosine_direction(Rng& g) {  // vec3.rs:257-
     const float r2 = g.random();
     const float z = sqrtf(1.0f - r2);
     const float phi = kTau * r1;
-    const float x = cosf(phi) * sqrtf(r2);
-    const float y = sinf(phi) * sqrtf(r2);
+    float sn, cs;  // one argument reduction for both (the values are those of sinf and cosf)
+    sincosf(phi, &sn, &cs);
+    const float x = cs * sqrtf(r2);
+    const float y = sn * sqrtf(r2);
     return mk3(x, y, z);
 }
 __device__ __forceinline__ float reflectance(float cosin, float ref_idx) {  // material.rs:116-120
