@@ -867,7 +867,8 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? k_wf_traverse<COUNT_PRODUCTION>
                                       : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE> : k_wf_traverse<COUNT_OFF>;
     const FinishKernel k_finish = count == COUNT_PRODUCTION ? k_wf_finish<COUNT_PRODUCTION>
-                                  : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE> : k_wf_finish<COUNT_OFF>;
+                                  : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE>
+                                  : ctx->has_general_subtrees ? k_wf_finish<COUNT_OFF> : k_wf_finish<COUNT_OFF, false>;
     int grid_full = 0;
     if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_traverse), &grid_full)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;

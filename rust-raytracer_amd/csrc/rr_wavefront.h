@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 // path, and the queue is claimed a chunk at a time per wave as in k_wf_traverse.  (Letting the lanes of a
 // wave run out of step as well — traversal moves, shading and refills whenever enough lanes wait for one —
 // was measured equal on the Suzanne scene and 4-10 % slower on final_scene.)
-template <int COUNT>
+template <int COUNT, bool GENERAL = true>  // GENERAL = false: without the general subtree machine, as for k_wf_paths
 __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
                                                                                 WfCtl* ctl, unsigned long long* counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
         const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
         float t_hit;
         uint32_t ref_hit;
-        traverse_parking<COUNT>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, 0u, cnt, t_hit, ref_hit);
+        traverse_parking<COUNT, GENERAL>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, 0u, cnt, t_hit, ref_hit);
         draws = g.n;
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
