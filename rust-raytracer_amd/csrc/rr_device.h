@@ -939,12 +939,12 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
 // scalar load per op; BVH subtrees and anything else that is data dependent are single ops
 // that hand a subtree to the per-lane machine.  Op words: w0 = code | flags << 8, w1 = ref,
 // w2..w7 = six f32 operands.
-constexpr uint32_t OP_END = 0, OP_RESET = 1, OP_TRANSLATE = 2, OP_ROT_X = 3, OP_ROT_Y = 4, OP_ROT_Z = 5, OP_RECT_XY = 6,
+constexpr uint32_t OP_END = 0, /* 1..5: the single transforms OP_XFORM replaced */ OP_RECT_XY = 6,
                    OP_RECT_XZ = 7, OP_RECT_YZ = 8, OP_SPHERE = 9, OP_LEAF_REF = 10, OP_SUBTREE = 11, OP_MED_BEGIN = 12,
                    OP_MED_MID = 13, OP_MED_END = 14, OP_CUBOID = 15, OP_SUBTREE_SIMPLE = 16, OP_MED_SPHERE = 17, OP_XFORM = 18;
-constexpr uint32_t OPF_COUNT_VISIT = 1u << 8;  // this transform is an instance being entered (counts as a visit)
-// OP_XFORM: a run of OP_RESET, OP_TRANSLATE, OP_ROT_* in that order (each at most once) as one op: an op of three
-// instructions costs a wave as much to fetch and dispatch as one of a hundred.  Translation in f0..f2, (sin, cos) in f3, f4.
+// OP_XFORM: back to the world ray (reset), a translation, a rotation about an axis, in that order and each at most once, as
+// one op: the ops of an instance chain being entered or left.  An op of three instructions costs a wave as much to fetch
+// and dispatch as one of a hundred.  Translation in f0..f2, (sin, cos) in f3, f4.
 constexpr uint32_t OPX_RESET = 1u << 8, OPX_TRANSLATE = 1u << 9, OPX_COUNT_TRANSLATE = 1u << 10, OPX_COUNT_ROT = 1u << 11,
                    OPX_ROT_SHIFT = 12;  // two bits: 0 no rotation, 1 + axis otherwise
 
@@ -1076,28 +1076,6 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
         } else if (code == OP_XFORM) {
             const uint32_t visits = xform_op(op, uni(op.code), wo, wd, o, d);
             if (COUNT && live) cnt.inst_visits += visits;
-        } else if (code == OP_RESET) {
-            o = wo;
-            d = wd;
-        } else if (code == OP_TRANSLATE) {  // collider.rs:481
-            if (COUNT && live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
-            o = o - mk3(op.f0, op.f1, op.f2);
-        } else if (code >= OP_ROT_X && code <= OP_ROT_Z) {  // collider.rs:499-509
-            if (COUNT && live && (uni(op.code) & OPF_COUNT_VISIT)) cnt.inst_visits++;
-            const float s = op.f0, c = op.f1;
-            f3 no = o, nd = d;
-            if (code == OP_ROT_Y) {
-                no.x = c * o.x - s * o.z, no.z = s * o.x + c * o.z;
-                nd.x = c * d.x - s * d.z, nd.z = s * d.x + c * d.z;
-            } else if (code == OP_ROT_X) {
-                no.y = c * o.y - s * o.z, no.z = s * o.y + c * o.z;
-                nd.y = c * d.y - s * d.z, nd.z = s * d.y + c * d.z;
-            } else {
-                no.x = c * o.x - s * o.y, no.y = s * o.x + c * o.y;
-                nd.x = c * d.x - s * d.y, nd.y = s * d.x + c * d.y;
-            }
-            o = no;
-            d = nd;
         } else if (code == OP_SPHERE) {
             if (COUNT && live) cnt.sphere_tests++;
             float t;
@@ -1380,29 +1358,6 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             } else if (code == OP_XFORM) {
                 const uint32_t visits = xform_op(op, uni(op.code), wo, wd, s.o, s.d);
                 if (COUNT && s.live) pcnt.inst_visits += visits;
-            } else if (code == OP_RESET) {
-                s.o = wo;
-                s.d = wd;
-            } else if (code == OP_TRANSLATE) {  // collider.rs:481
-                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) pcnt.inst_visits++;
-                s.o = s.o - mk3(op.f0, op.f1, op.f2);
-            } else if (code >= OP_ROT_X && code <= OP_ROT_Z) {  // collider.rs:499-509
-                if (COUNT && s.live && (uni(op.code) & OPF_COUNT_VISIT)) pcnt.inst_visits++;
-                const float sn = op.f0, c = op.f1;
-                const f3 o = s.o, d = s.d;
-                f3 no = o, nd = d;
-                if (code == OP_ROT_Y) {
-                    no.x = c * o.x - sn * o.z, no.z = sn * o.x + c * o.z;
-                    nd.x = c * d.x - sn * d.z, nd.z = sn * d.x + c * d.z;
-                } else if (code == OP_ROT_X) {
-                    no.y = c * o.y - sn * o.z, no.z = sn * o.y + c * o.z;
-                    nd.y = c * d.y - sn * d.z, nd.z = sn * d.y + c * d.z;
-                } else {
-                    no.x = c * o.x - sn * o.y, no.y = sn * o.x + c * o.y;
-                    nd.x = c * d.x - sn * d.y, nd.y = sn * d.x + c * d.y;
-                }
-                s.o = no;
-                s.d = nd;
             } else if (code == OP_SPHERE) {
                 if (COUNT && s.live) pcnt.sphere_tests++;
                 float t;

@@ -622,12 +622,14 @@ struct ProgramBuilder {
     }
     void xform(uint32_t ii, bool entering) {
         const rr_instance& in = s.instances[ii];
-        const uint32_t flag = entering ? OPF_COUNT_VISIT : 0u;
+        const bool flag = entering;  // an instance being entered counts as a visit
+        // (one-part OP_XFORMs; fuse_transforms merges the runs)
         if (in.kind == RR_INST_TRANSLATE)
-            ops.push_back(make(OP_TRANSLATE | flag, NONE, in.v[0], in.v[1], in.v[2]));
+            ops.push_back(make(OP_XFORM | OPX_TRANSLATE | (flag ? OPX_COUNT_TRANSLATE : 0u), NONE, in.v[0], in.v[1], in.v[2]));
         else
-            ops.push_back(make((in.kind == RR_INST_ROTATE_X ? OP_ROT_X : in.kind == RR_INST_ROTATE_Y ? OP_ROT_Y : OP_ROT_Z) | flag,
-                               NONE, in.v[0], in.v[1]));
+            ops.push_back(make(OP_XFORM | ((in.kind == RR_INST_ROTATE_X ? 1u : in.kind == RR_INST_ROTATE_Y ? 2u : 3u) << OPX_ROT_SHIFT) |
+                                   (flag ? OPX_COUNT_ROT : 0u),
+                               NONE, 0.f, 0.f, 0.f, in.v[0], in.v[1]));
     }
     // Make the ray space of the next op equal to `chain`, always recomputing from the world ray.
     void ensure_space() {
@@ -635,35 +637,36 @@ struct ProgramBuilder {
         size_t common = 0;
         while (common < space.size() && common < chain.size() && space[common] == chain[common]) ++common;
         if (common != space.size()) {  // leaving a space cannot be undone exactly: start again from the world ray
-            ops.push_back(make(OP_RESET));
+            ops.push_back(make(OP_XFORM | OPX_RESET));
             common = 0;
         }
         for (size_t k = common; k < chain.size(); ++k) xform(chain[k], false);
         space = chain;
     }
-    // Runs of OP_RESET, OP_TRANSLATE, OP_ROT_* (in that order, each at most once) become one OP_XFORM each.
+    // Runs of one-part OP_XFORMs in the order reset, translate, rotate (each at most once) become one OP_XFORM each.
     void fuse_transforms() {
         std::vector<Op> out;
+        auto parts = [](const Op& o) { return o.code & (OPX_RESET | OPX_TRANSLATE | (3u << OPX_ROT_SHIFT)); };
         for (size_t i = 0; i < ops.size();) {
-            auto code_at = [&](size_t k) { return k < ops.size() ? (ops[k].code & 0xFFu) : OP_END; };
-            auto is_rot = [&](uint32_t c) { return c >= OP_ROT_X && c <= OP_ROT_Z; };
-            const uint32_t c0 = code_at(i);
-            if (c0 != OP_RESET && c0 != OP_TRANSLATE && !is_rot(c0)) {
+            if ((ops[i].code & 0xFFu) != OP_XFORM) {
                 out.push_back(ops[i++]);
                 continue;
             }
-            Op x = make(OP_XFORM);
-            size_t n = 0;
-            if (code_at(i) == OP_RESET) x.code |= OPX_RESET, ++i, ++n;
-            if (code_at(i) == OP_TRANSLATE) {
-                x.code |= OPX_TRANSLATE | ((ops[i].code & OPF_COUNT_VISIT) ? OPX_COUNT_TRANSLATE : 0u);
-                x.f0 = ops[i].f0, x.f1 = ops[i].f1, x.f2 = ops[i].f2;
-                ++i, ++n;
-            }
-            if (is_rot(code_at(i))) {
-                x.code |= ((code_at(i) - OP_ROT_X + 1u) << OPX_ROT_SHIFT) | ((ops[i].code & OPF_COUNT_VISIT) ? OPX_COUNT_ROT : 0u);
-                x.f3 = ops[i].f0, x.f4 = ops[i].f1;
-                ++i, ++n;
+            Op x = ops[i++];
+            // what may still follow in this op: translate after reset; rotate after reset or translate
+            while (i < ops.size() && (ops[i].code & 0xFFu) == OP_XFORM) {
+                const uint32_t have = parts(x), next = parts(ops[i]);
+                const bool t_next = next == OPX_TRANSLATE, r_next = (next & (3u << OPX_ROT_SHIFT)) != 0u && (next & ~(3u << OPX_ROT_SHIFT)) == 0u;
+                if (t_next && !(have & (OPX_TRANSLATE | (3u << OPX_ROT_SHIFT)))) {
+                    x.code |= ops[i].code & (OPX_TRANSLATE | OPX_COUNT_TRANSLATE);
+                    x.f0 = ops[i].f0, x.f1 = ops[i].f1, x.f2 = ops[i].f2;
+                } else if (r_next && !(have & (3u << OPX_ROT_SHIFT))) {
+                    x.code |= ops[i].code & ((3u << OPX_ROT_SHIFT) | OPX_COUNT_ROT);
+                    x.f3 = ops[i].f3, x.f4 = ops[i].f4;
+                } else {
+                    break;
+                }
+                ++i;
             }
             out.push_back(x);
         }
@@ -1308,7 +1311,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     pb.ops.push_back(ProgramBuilder::make(OP_END));
     pb.ops.push_back(ProgramBuilder::make(OP_END));  // the interpreter prefetches one op past the one it runs
     if (std::getenv("RR_DUMP_PROGRAM")) {  // for whoever tunes the program: its ops, one per line, to stderr
-        static const char* const names[] = {"END", "RESET", "TRANSLATE", "ROT_X", "ROT_Y", "ROT_Z", "RECT_XY", "RECT_XZ", "RECT_YZ", "SPHERE", "LEAF_REF",
+        static const char* const names[] = {"END", "-", "-", "-", "-", "-", "RECT_XY", "RECT_XZ", "RECT_YZ", "SPHERE", "LEAF_REF",
                                             "SUBTREE", "MED_BEGIN", "MED_MID", "MED_END", "CUBOID", "SUBTREE_SIMPLE", "MED_SPHERE", "XFORM"};
         for (size_t i = 0; i < pb.ops.size(); ++i) {
             const Op& o = pb.ops[i];
@@ -1376,7 +1379,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         // (the fused ops count as the ops they stand for)
         if (code == OP_MED_SPHERE) top_ops += 5u;
         else if (code == OP_XFORM) top_ops += ((op.code & OPX_TRANSLATE) ? 1u : 0u) + (((op.code >> OPX_ROT_SHIFT) & 3u) ? 1u : 0u);
-        else top_ops += !subtree && code != OP_END && code != OP_RESET;
+        else top_ops += !subtree && code != OP_END;
     }
     // Scenes with BVH subtrees: when nearly everything is inside the subtrees, the bounce kernels of the wavefront
     // pipeline (pure traversal at twice the occupancy) are the faster way through the camera rays; when the scene
