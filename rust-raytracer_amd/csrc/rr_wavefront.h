@@ -119,10 +119,10 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 }
 
 #ifndef RR_WF_FINISH_PARK_BELOW
-#define RR_WF_FINISH_PARK_BELOW 12  // lanes still descending in a subtree are parked once fewer than this many are left
+#define RR_WF_FINISH_PARK_BELOW 20  // lanes still descending in a subtree are parked once fewer than this many are left
 #endif
 #ifndef RR_WF_FINISH_PARK_MIN_STEPS
-#define RR_WF_FINISH_PARK_MIN_STEPS 4  // machine steps a visit of a subtree takes at least, so that parked lanes get on
+#define RR_WF_FINISH_PARK_MIN_STEPS 6  // machine steps a visit of a subtree takes at least, so that parked lanes get on
 #endif
 #ifndef RR_WF_FINISH_PARK_MIN_FRESH
 #define RR_WF_FINISH_PARK_MIN_FRESH 8  // with the queue drained and fewer lanes than this starting a ray, nothing is parked
