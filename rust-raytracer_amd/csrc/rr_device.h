@@ -1156,10 +1156,14 @@ struct ProgState {
     }
 };
 
-constexpr uint32_t PARK_SLOTS = 24;  // parked lanes a wave can hold
+#ifndef RR_PARK_SLOTS
+#define RR_PARK_SLOTS 24
+#endif
+constexpr uint32_t PARK_SLOTS = RR_PARK_SLOTS;  // parked lanes a wave can hold (at most 31: one bit each of a 32-bit mask)
 constexpr uint32_t PARK_WORDS = 22;  // machine: o, d, tmin, tmax, cur, node, sp and flags; program: o, d, tmin, the open medium's four
 constexpr uint32_t PARK_LDS_WORDS_PER_WAVE = PARK_SLOTS * PARK_WORDS;
 constexpr uint32_t PARK_PC_MASK = 0xFFFFFFu;
+constexpr uint32_t TRIANGLE_MIN_STEPS = 3;  // see traverse_parking
 struct ParkArea {        // wave-uniform
     uint32_t* slots;     // word w of slot k at slots[w * PARK_SLOTS + k]
     uint32_t free_mask;  // bit k: slot k is free
@@ -1289,7 +1293,10 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             asm volatile("" ::"s"(left), "s"(right));
             if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
             const bool in = enter || rejoin;
-            uint32_t steps = 0;
+            // (a visit of a subtree over triangles counts from a head start: at least TRIANGLE_MIN_STEPS instead of min_steps.
+            // Most rays are done with a mesh in two or three moves, so that the steps a visit is made to take run with few lanes:
+            // Suzanne +2.9 %, the 1.1 M-primitive mesh +3 %)
+            uint32_t steps = (cls == BVH_CLASS_CULL_ANY_T && min_steps > TRIANGLE_MIN_STEPS) ? min_steps - TRIANGLE_MIN_STEPS : 0u;
             for (;;) {
                 const bool going = in && !m.finished();
                 const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
