@@ -113,6 +113,25 @@ struct DevScene {  // kernel argument
     const RR_CONST_AS DevConst* k;
 };
 
+// The kernel arguments arrive by wide scalar loads, eight registers at a time, and the compiler keeps such a group together: when
+// it runs out of scalar registers it spills and reloads all eight (a v_readlane each, in the traversal loop) for the one
+// pointer a move needs.  A move through an instruction the compiler cannot look into makes each pointer the traversal loop
+// uses a value of its own.
+template <class T>
+__device__ __forceinline__ void own_register_pair(const T*& p) {
+    uint64_t from = reinterpret_cast<uint64_t>(p), to;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(to) : "s"(from));
+    // (named a pointer to global memory again: what comes out of the asm would otherwise be loaded from with flat instructions)
+    p = (const T*)reinterpret_cast<const __attribute__((address_space(1))) T*>(to);
+}
+__device__ __forceinline__ void own_registers(DevScene& sc) {
+    own_register_pair(sc.bvh);
+    own_register_pair(sc.sphere);
+    own_register_pair(sc.rect);
+    own_register_pair(sc.tri);
+    own_register_pair(sc.cuboid);
+}
+
 struct Counts {
     uint32_t rays, box_tests, sphere_tests, rect_tests, tri_tests, inst_visits, samples;
     uint32_t lane_steps, wave_steps;  // steps of the per-lane traversal machine: (lane, step) pairs that moved; steps of the wave (counted on one lane)
@@ -162,6 +181,13 @@ struct Rng {
     }
     __device__ __forceinline__ void refill() {
         uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = n >> 2, ka = k0, kb = k1;
+#ifndef RR_PHILOX_HOIST_KEYS
+        // The key is the seed, a kernel argument, so the ten round keys are the same for every block of a launch, and the
+        // compiler would form them once and hold all twenty in scalar registers from one end of the kernel to the other:
+        // registers the traversal loops then lack (what does not fit is spilled to lanes of a vector register and read back with
+        // a v_readlane per use).  Behind an empty asm the round keys are twenty scalar additions where a block is made.
+        asm volatile("" : "+s"(ka), "+s"(kb));
+#endif
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
             uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;

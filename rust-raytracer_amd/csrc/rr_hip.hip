@@ -867,11 +867,14 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
     using TraverseKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, uint32_t, unsigned long long*);
     using FinishKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, unsigned long long*);
+    const bool ref_sem = ctx->sc.intended == 0u;  // (the production kernels have a build that knows the semantics switch is off)
     const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? k_wf_traverse<COUNT_PRODUCTION>
-                                      : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE> : k_wf_traverse<COUNT_OFF>;
+                                      : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE>
+                                      : ref_sem ? k_wf_traverse<COUNT_OFF, true> : k_wf_traverse<COUNT_OFF>;
     const FinishKernel k_finish = count == COUNT_PRODUCTION ? k_wf_finish<COUNT_PRODUCTION>
                                   : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE>
-                                  : ctx->has_general_subtrees ? k_wf_finish<COUNT_OFF> : k_wf_finish<COUNT_OFF, false>;
+                                  : ctx->has_general_subtrees ? (ref_sem ? k_wf_finish<COUNT_OFF, true, true> : k_wf_finish<COUNT_OFF>)
+                                                              : (ref_sem ? k_wf_finish<COUNT_OFF, false, true> : k_wf_finish<COUNT_OFF, false>);
     int grid_full = 0;
     if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(k_traverse), &grid_full)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
@@ -978,7 +981,8 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     const PathsKernel kernel =
         ctx->has_subtrees ? (count == COUNT_PRODUCTION  ? k_wf_paths<COUNT_PRODUCTION, true, true>
                              : count == COUNT_REFERENCE ? k_wf_paths<COUNT_REFERENCE, true, true>
-                             : ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true> : k_wf_paths<COUNT_OFF, true, true, false>)
+                             : ctx->sc.intended != 0u ? (ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true> : k_wf_paths<COUNT_OFF, true, true, false>)
+                             : ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true, true, true> : k_wf_paths<COUNT_OFF, true, true, false, true>)
         : ctx->prog_vector_ops ? (count ? k_wf_paths<COUNT_REFERENCE, true> : k_wf_paths<COUNT_OFF, true>)
                                : (count ? k_wf_paths<COUNT_REFERENCE, false> : k_wf_paths<COUNT_OFF, false>);
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes

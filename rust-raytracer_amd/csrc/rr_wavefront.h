@@ -31,6 +31,7 @@
 #ifndef RR_WF_SHADE_WAVES_PER_SIMD
 #define RR_WF_SHADE_WAVES_PER_SIMD 3
 #endif
+constexpr uint32_t WF_BLOCK = 256;   // threads of a workgroup of every kernel here that keeps per-lane stacks in LDS (the hosts launch them so)
 constexpr uint32_t WF_STAGE = 1024;  // queue entries a shading wave collects before it appends them
 #ifndef RR_WF_LEAF_LANES
 #define RR_WF_LEAF_LANES 24  // lanes waiting at a leaf that make the wave take the leaf move at once
@@ -140,12 +141,17 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true>
-__global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc, WfArgs a, float4* __restrict__ values,
+template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false>
+__global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc_arg, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
+    // REF_SEM: a build that is only launched for scenes with the reference's own semantics, so that the switch is a constant
+    // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
+    DevScene sc = sc_arg;
+    if (REF_SEM) sc.intended = 0u;
+    if (PARK) own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
-    const uint32_t stride = blockDim.x;
+    constexpr uint32_t stride = WF_BLOCK;  // word w of a lane's stack is at stk[w * stride]: a shift, not a multiplication by a register
     Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
     bool exhausted = a.n_paths == 0;        // wave-uniform: no unclaimed paths are left for anyone
@@ -158,7 +164,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevS
     ParkArea pa;
     uint32_t park = NONE;  // the slot and op this lane's path is parked at
     uint32_t draws = 0;
-    if (PARK) pa.init(lds_stack + a.stack_words * blockDim.x);
+    if (PARK) pa.init(lds_stack + a.stack_words * WF_BLOCK);
     // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
     // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
     for (;;) {
@@ -270,13 +276,15 @@ struct WfDraw {
     }
 };
 
-template <int COUNT>
+template <int COUNT, bool REF_SEM = false>  // REF_SEM: as for k_wf_paths
 __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
-    k_wf_traverse(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
+    k_wf_traverse(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
                   unsigned long long* counters) {
+    DevScene sc = sc_arg;
+    if (REF_SEM) sc.intended = 0u;
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
-    const uint32_t stride = blockDim.x;
+    constexpr uint32_t stride = WF_BLOCK;
     const uint32_t total = ctl->count;
     Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     Trav m;
@@ -471,12 +479,15 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 // path, and the queue is claimed a chunk at a time per wave as in k_wf_traverse.  (Letting the lanes of a
 // wave run out of step as well — traversal moves, shading and refills whenever enough lanes wait for one —
 // was measured equal on the Suzanne scene and 4-10 % slower on final_scene.)
-template <int COUNT, bool GENERAL = true>  // GENERAL = false: without the general subtree machine, as for k_wf_paths
-__global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
+template <int COUNT, bool GENERAL = true, bool REF_SEM = false>  // GENERAL = false: without the general subtree machine; REF_SEM: as for k_wf_paths
+__global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
                                                                                 WfCtl* ctl, unsigned long long* counters) {
+    DevScene sc = sc_arg;
+    if (REF_SEM) sc.intended = 0u;
+    own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
-    const uint32_t stride = blockDim.x;
+    constexpr uint32_t stride = WF_BLOCK;
     const uint32_t total = ctl->count;
     Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint32_t n_waves = gridDim.x * (blockDim.x / 64u);
@@ -488,7 +499,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
     f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(1.f, 1.f, 1.f), thr = mk3(0.f, 0.f, 0.f);
     float time = 0.f;
     ParkArea pa;
-    pa.init(lds_stack + a.stack_words * blockDim.x);
+    pa.init(lds_stack + a.stack_words * WF_BLOCK);
     uint32_t park = NONE;  // the slot and op this lane's path is parked at
     for (;;) {
         const uint64_t idle = __ballot(!have);
