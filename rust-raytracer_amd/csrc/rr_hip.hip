@@ -352,6 +352,12 @@ struct Below {
     bool has_tri = false;  // triangles accept hits outside the caller's t range (collider.rs:627)
     bool has_medium = false;
     bool simple = true;    // nothing but BVH nodes over spheres, rects, triangles and cuboids
+    float box_lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, box_hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};  // union of the stored boxes of the BVH nodes below
+    bool boxes_inside(const rr_bvh_node& n) const {  // the stored box of `n` holds the stored box of every BVH node below
+        for (int a = 0; a < 3; ++a)
+            if (box_lo[a] <= box_hi[a] && !(n.bmin[a] <= box_lo[a] && box_hi[a] <= n.bmax[a])) return false;
+        return true;
+    }
     void add_point(double x, double y, double z) {
         const double p[3] = {x, y, z};
         for (int a = 0; a < 3; ++a) {
@@ -364,6 +370,10 @@ struct Below {
         for (int a = 0; a < 3; ++a) {
             lo[a] = std::min(lo[a], o.lo[a]);
             hi[a] = std::max(hi[a], o.hi[a]);
+        }
+        for (int a = 0; a < 3; ++a) {
+            box_lo[a] = std::min(box_lo[a], o.box_lo[a]);
+            box_hi[a] = std::max(box_hi[a], o.box_hi[a]);
         }
         bounded &= o.bounded;
         has_tri |= o.has_tri;
@@ -559,6 +569,13 @@ struct Walker {
                 below = bl;
                 below.merge(br);
                 bvh_below[idx] = below;
+                if (n.has_box) {  // (what the caller sees below it includes this node's own box; a box with a NaN holds nothing and is held by nothing)
+                    for (int a = 0; a < 3; ++a) {
+                        const bool finite = n.bmin[a] == n.bmin[a] && n.bmax[a] == n.bmax[a];
+                        below.box_lo[a] = finite ? std::min(below.box_lo[a], n.bmin[a]) : -3.0e38f;
+                        below.box_hi[a] = finite ? std::max(below.box_hi[a], n.bmax[a]) : 3.0e38f;
+                    }
+                }
                 words = FRAME_WORDS_BVH + std::max(wl, wr);
                 return true;
             }
@@ -740,7 +757,10 @@ struct ProgramBuilder {
             default: {  // RR_TAG_BVH
                 ensure_space();
                 const rr_bvh_node& n = s.bvh_nodes[idx];
-                if (bvh_below[idx].simple && n.has_box)  // the root's box and class travel in the op: its test is made before the descent is handed out
+                // the root's box and class travel in the op: its test is made before the descent is handed out, and the margin
+                // of the culling test is formed once per visit from that box, which must then hold every box below it (the boxes
+                // of a tree built bottom-up from surrounding boxes do, collider.rs:205-211; any other tree takes the general machine)
+                if (bvh_below[idx].simple && n.has_box && bvh_below[idx].boxes_inside(n))
                     ops.push_back(make(OP_SUBTREE_SIMPLE | (static_cast<uint32_t>(bvh_class[idx]) << 8), dref(tag, idx), n.bmin[0], n.bmin[1], n.bmin[2],
                                        n.bmax[0], n.bmax[1], n.bmax[2]));
                 else

@@ -474,8 +474,11 @@ def test_intersection_counters_match_oracle(gpu_ctx):
 @pytest.mark.parametrize("name", ["cornell", "spheres", "suzanne", "final"])
 def test_production_counters_count_the_production_traversal(gpu_ctx, name):
     """RR_FLAG_COUNT_PRODUCTION switches the counters on without changing the traversal: same image as without flags,
-    the same counts from every kernel organisation, never more tests than the reference-order count, and far fewer box
-    tests wherever BVH subtrees are culled."""
+    never more tests than the reference-order count, and far fewer box tests wherever BVH subtrees are culled.  The kernel
+    organisations agree on rays, samples and instance visits exactly and on the tests within 3 %: the culling test of the
+    kernels that enter a subtree from the scene program grows every box of the subtree by the margin of the subtree's root,
+    the machine that walks the whole tree by each node's own (smaller) margin, so the former enter a few more nodes whose
+    boxes the ray only just misses (and find nothing there: the images are the same bits)."""
     b, flat, _ = config_scene(name)
     gpu_ctx.upload(flat)
     kw = dict(n_slices=2, max_depth=30, seed=29)
@@ -498,7 +501,9 @@ def test_production_counters_count_the_production_traversal(gpu_ctx, name):
     for flags in (abi.FLAG_PATHS, abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT):
         other = gpu_ctx.render(device.make_params(60, 44, 6, flags=flags | abi.FLAG_COUNT_PRODUCTION, **kw))
         assert np.array_equal(plain["slice_sums"], other["slice_sums"], equal_nan=True)
-        assert counts(other) == counts(prod), flags
+        co = counts(other)
+        for k, v in counts(prod).items():
+            assert co[k] == v if k in ("rays", "samples", "inst_visits") else abs(co[k] - v) <= 0.03 * v, (flags, k, co[k], v)
     with pytest.raises(device.DeviceError, match="exclude"):
         gpu_ctx.render(device.make_params(8, 8, 2, flags=abi.FLAG_COUNTERS | abi.FLAG_COUNT_PRODUCTION))
 
