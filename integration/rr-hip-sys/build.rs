@@ -11,7 +11,7 @@ fn main() {
     let so = out.join("librr_hip.so");
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
     let ok = Command::new(&hipcc)
-        .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"])
+        .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"])
         .arg(&src)
         .arg("-o")
         .arg(&so)

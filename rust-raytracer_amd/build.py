@@ -15,7 +15,12 @@ INCLUDE = os.path.join(abi.REPO_DIR, "include")
 # -ffp-contract=off: the path's arithmetic contract is one IEEE f32 operation per source
 # operation, as in the reference's Rust (no fused multiply-add), so that ids, t and normals
 # agree with the CPU oracle bit for bit.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+# -fno-slp-vectorize: left to itself the compiler pairs independent f32 operations of the intersectors into packed
+# instructions (v_pk_mul_f32, v_pk_add_f32), whose operands must sit in adjacent registers: in these kernels that cost about 300
+# register moves and the registers to hold the pairs (the path kernel spilled 24 of them; without the pairing none), for
+# instructions that issue at the rate of the two they replace.  Measured: final_scene +8.5 %, Suzanne +9.7 %, random spheres
+# +11 %, Cornell box +4.4 %, the 1.1 M-primitive mesh +6 %; same bits.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall"]
 GXX_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra"]
 
 

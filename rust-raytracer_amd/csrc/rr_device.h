@@ -570,22 +570,16 @@ __device__ __forceinline__ void node_descend(const DevScene& sc, Trav& m, uint32
     // Under the labelled intended semantics (src/bvh.rs:19-44) the other child follows the first after a hit and after a
     // miss alike, and a span-1 node's second visit is only left out where it cannot draw random numbers (its classes say so).
     const bool pure = cls >= BVH_CLASS_CULL_RANGE;
-    if (pure && l == r) {
-        m.node = l;  // span-1 node: the second visit repeats the first
-    } else {
-        uint32_t fw;
-        if (!dirpos)
-            fw = l;  // right first; left follows after a hit and after a miss alike
-        else if (sc.intended != 0u)
-            fw = r;
-        else if (pure)
-            fw = r | FW_MISS_NONE;  // left first; the re-test of left after a miss misses again
-        else
-            fw = frame_word(FK_BVH2, idx);
+    // what follows `left` when it went first: `right` (after a hit only: the re-test of left after a miss misses again), or the
+    // node's frame, which decides after left came back; when `right` went first, left follows after a hit and after a miss alike
+    const uint32_t after_left = sc.intended != 0u ? r : (pure ? (r | FW_MISS_NONE) : frame_word(FK_BVH2, idx));
+    const uint32_t fw = dirpos ? after_left : l;
+    m.node = dirpos ? l : r;
+    // (straight-line code with one predicated store: as nested ifs this was three levels of scalar branches per node)
+    if (!(pure && l == r)) {  // a span-1 node's second visit repeats the first: no frame
         stk[m.sp * stride] = fw | (m.hitf ? FW_FLAG : 0u);
         m.sp += 1;
         m.hitf = false;
-        m.node = dirpos ? l : r;
     }
 }
 
@@ -1354,6 +1348,9 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                     if (at_leaf) trav_leaf_simple<COUNT>(sc, m, cnt);
                 }
                 if (going) trav_pop_simple(sc, m, stk, stride);
+#ifdef RR_POP_TWICE
+                if (going) trav_pop_simple(sc, m, stk, stride);
+#endif
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
