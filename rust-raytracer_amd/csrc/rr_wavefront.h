@@ -141,8 +141,12 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false>
-__global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_wf_paths(DevScene sc_arg, WfArgs a, float4* __restrict__ values,
+// WAVES: waves per SIMD the register allocator leaves room for (4: 128 vector registers, 5: 102).  Measured once the build
+// no longer paired f32 operations (which had cost registers): 5 is +9.5 % on the Cornell box and +3.3 % on final_scene,
+// -2 % on Suzanne (the triangle test is what needs the registers), 6 is worse everywhere: the host picks 5 for scenes
+// without triangles.
+template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     // REF_SEM: a build that is only launched for scenes with the reference's own semantics, so that the switch is a constant
     // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
