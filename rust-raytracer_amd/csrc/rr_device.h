@@ -140,6 +140,17 @@ struct Counts {
 // in its order, and counts them; COUNT_PRODUCTION counts what the production traversal (visit skipping, culling) does.
 constexpr int COUNT_OFF = 0, COUNT_REFERENCE = 1, COUNT_PRODUCTION = 2;
 
+// Wave votes.  RR_VOTE_BUILTIN: on a bool through the compiler's builtin (the lane mask of the comparison itself) instead of
+// HIP's __ballot(int), which first makes an integer of the bool and compares it with zero (two vector instructions a vote).
+// Measured twice, before and after the kernels stopped spilling registers: -2 % on final_scene both times, so it is off.
+#ifdef RR_VOTE_BUILTIN
+#define RR_BALLOT(x) __builtin_amdgcn_ballot_w64(static_cast<bool>(x))
+#define RR_ANY(x) (__builtin_amdgcn_ballot_w64(static_cast<bool>(x)) != 0ull)
+#else
+#define RR_BALLOT(x) __ballot(x)
+#define RR_ANY(x) __any(x)
+#endif
+
 // ------------------------------------------------------------------ math
 struct f3 {
     float x, y, z;
@@ -1233,13 +1244,13 @@ __device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, Pro
 // are parked at `this_pc`, in the slot they have or in a free one.  Wave-uniform control flow.
 __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Trav& m, uint32_t& slot, bool in, uint32_t this_pc, bool& act) {
     const bool done = in && m.finished();
-    uint64_t fm = __ballot(done && s.parked);  // slots coming back
+    uint64_t fm = RR_BALLOT(done && s.parked);  // slots coming back
     while (fm != 0) {
         const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(fm));
         fm &= fm - 1;
         pa.free_mask |= 1u << __builtin_amdgcn_readlane(slot, l);
     }
-    uint64_t nm = __ballot(in && !done && !s.parked);  // lanes parked for the first time
+    uint64_t nm = RR_BALLOT(in && !done && !s.parked);  // lanes parked for the first time
     while (nm != 0) {
         const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(nm));
         nm &= nm - 1;
@@ -1291,7 +1302,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
     // a visit may end with lanes still descending only while there are slots for the ones that have none yet
     auto may_park = [&](bool going, uint32_t n, uint32_t steps) {
         if (!(n < park_below && steps >= min_steps)) return false;
-        return static_cast<uint32_t>(__popcll(__ballot(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
+        return static_cast<uint32_t>(__popcll(RR_BALLOT(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
     for (;;) {  // (the counted loop of traverse measured slower here: -1.5 % final_scene, -4.6 % Suzanne; this kernel has no scalar registers to spare)
         const Op op = next;
@@ -1336,13 +1347,13 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             uint32_t steps = (cls == BVH_CLASS_CULL_ANY_T && min_steps > TRIANGLE_MIN_STEPS) ? min_steps - TRIANGLE_MIN_STEPS : 0u;
             for (;;) {
                 const bool going = in && !m.finished();
-                const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
+                const uint32_t n = static_cast<uint32_t>(__popcll(RR_BALLOT(going)));
                 if (n == 0 || may_park(going, n, steps)) break;
                 // A leaf move is the dearest of the three and usually only a few lanes are at a leaf: those wait, while other
                 // lanes can still move, until they are at least one in `leaf_wait` of the lanes descending (0: nobody waits).
                 if (going) trav_node<COUNT, SUBTREE_MARGIN>(sc, m, stk, stride, cnt);
                 const bool at_leaf = going && trav_at_leaf(m);
-                const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
+                const uint32_t n_leaf = static_cast<uint32_t>(__popcll(RR_BALLOT(at_leaf)));
                 // (when every lane that descends is at a leaf, n_leaf == n, the test holds whatever the fraction)
                 if (leaf_wait == 0u || n_leaf * leaf_wait >= n) {
                     if (at_leaf) trav_leaf_simple<COUNT>(sc, m, cnt);
@@ -1369,7 +1380,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             uint32_t steps = 0;
             for (;;) {
                 const bool going = in && !m.finished();
-                const uint32_t n = static_cast<uint32_t>(__popcll(__ballot(going)));
+                const uint32_t n = static_cast<uint32_t>(__popcll(RR_BALLOT(going)));
                 if (n == 0 || may_park(going, n, steps)) break;
                 if (going) trav_step<COUNT>(sc, m, world, rng, stk, stride, cnt);
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
         // ---- lanes without an item take the next unclaimed ones
         for (;;) {
             const bool need = !path_active && !have_item && !lane_done;
-            const uint64_t mask = __ballot(need);
+            const uint64_t mask = RR_BALLOT(need);
             if (mask == 0) break;
             if (chunk_pos == chunk_end) {
                 unsigned long long base = 0;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
             path_active = true;
             cnt.samples++;
         }
-        if (!__any(path_active)) break;
+        if (!RR_ANY(path_active)) break;
         // ---- one ray_color call (render.rs:15-41) for every lane that has a path
         const bool run = path_active && depth_left != 0;
         if (run) cnt.rays++;

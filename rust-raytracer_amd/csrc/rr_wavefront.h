@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
     // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
     for (;;) {
-        const uint64_t idle = __ballot(!path_active);
+        const uint64_t idle = RR_BALLOT(!path_active);
         if (!exhausted && idle != 0) {
             if (chunk_pos == chunk_end) {
                 uint32_t base = 0;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             chunk_pos += take;
             exhausted = chunk_pos == chunk_end && chunk_end == a.n_paths;  // the counter only grows
         }
-        if (!__any(path_active)) {
+        if (!RR_ANY(path_active)) {
             if (exhausted) break;
             continue;
         }
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
         if (PARK) {
             g.n = draws;
             if (g.n & 3u) g.refill();
-            const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && !was_parked)));
+            const uint32_t n_fresh = static_cast<uint32_t>(__popcll(RR_BALLOT(run && !was_parked)));
             const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
             traverse_parking<COUNT, GENERAL>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
             draws = g.n;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     // Every lane leaves through the same wave-wide vote, after the queue is drained and the last
     // ray of the wave has finished.
     for (;;) {
-        const uint64_t idle = __ballot(!active);
+        const uint64_t idle = RR_BALLOT(!active);
         if (!exhausted && __popcll(idle) >= RR_WF_REFILL_IDLE) {
             if (chunk_pos == chunk_end) {
                 uint32_t base = 0;
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                 }
             }
         }
-        if (!__any(active)) {
+        if (!RR_ANY(active)) {
             if (exhausted) break;
             continue;
         }
@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
         if (COUNT) cnt.lane_steps += active ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
         if (active) trav_node<COUNT>(sc, m, stk, stride, cnt);
         const bool at_leaf = active && trav_at_leaf(m);
-        const uint32_t n_leaf = static_cast<uint32_t>(__popcll(__ballot(at_leaf)));
-        const uint32_t n_node = static_cast<uint32_t>(__popcll(__ballot(active && trav_at_node(m))));
+        const uint32_t n_leaf = static_cast<uint32_t>(__popcll(RR_BALLOT(at_leaf)));
+        const uint32_t n_node = static_cast<uint32_t>(__popcll(RR_BALLOT(active && trav_at_node(m))));
         if (n_leaf != 0 && (n_leaf >= RR_WF_LEAF_LANES || n_leaf >= n_node)) {
             if (at_leaf) trav_leaf<COUNT>(sc, m, world, stk, stride, cnt);
         }
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
                 st.thr[p] = make_float4(c.x, c.y, c.z, 0.f);
             }
         }
-        const uint64_t mask = __ballot(keep);
+        const uint64_t mask = RR_BALLOT(keep);
         if (mask) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
             if (keep) stage[staged + rank] = p;
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
     pa.init(lds_stack + a.stack_words * WF_BLOCK);
     uint32_t park = NONE;  // the slot and op this lane's path is parked at
     for (;;) {
-        const uint64_t idle = __ballot(!have);
+        const uint64_t idle = RR_BALLOT(!have);
         if (!exhausted && idle != 0) {
             if (chunk_pos == chunk_end) {
                 uint32_t base = 0;
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                 draws = 0;
             }
         }
-        if (!__any(have)) {
+        if (!RR_ANY(have)) {
             if (exhausted) break;
             continue;
         }
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
         g.start(a.seed, pixel, sample, a.max_depth - depth_left);
         g.n = draws;
         if (g.n & 3u) g.refill();
-        const uint32_t n_fresh = static_cast<uint32_t>(__popcll(__ballot(run && park == NONE)));
+        const uint32_t n_fresh = static_cast<uint32_t>(__popcll(RR_BALLOT(run && park == NONE)));
         const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
         float t_hit;
         uint32_t ref_hit;
