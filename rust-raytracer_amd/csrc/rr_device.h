@@ -1359,10 +1359,10 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (leaf_wait == 0u || n_leaf * leaf_wait >= n) {
                     if (at_leaf) trav_leaf_simple<COUNT>(sc, m, cnt);
                 }
+                // (a second return in the same step for lanes whose first one found nothing to do: final_scene +0.1 %, Suzanne -0.8 %;
+                // the top word of the stack in a register, so that a return does not wait for LDS: -3 % everywhere, it costs a
+                // register and a store per push)
                 if (going) trav_pop_simple(sc, m, stk, stride);
-#ifdef RR_POP_TWICE
-                if (going) trav_pop_simple(sc, m, stk, stride);
-#endif
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
