@@ -304,6 +304,8 @@ typedef struct rr_scene_info {
                                        reference (a constant medium below, or a box that does not hold what is below),
                                        [2] redundant visits skipped and subtrees culled against [t_min,t_max],
                                        [3] the same against [0,inf) (triangles below)                              */
+    uint32_t subtree_ops[2]; /* BVH subtrees the scene program hands to the per-lane machine: [0] to the moves for BVH nodes over
+                                spheres, rects, triangles and cuboids whose root box holds every box below, [1] to the general machine */
 } rr_scene_info;
 
 typedef struct rr_context rr_context;

@@ -153,7 +153,7 @@ class Hit(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("stack_words", u32), ("max_inst_depth", u32), ("device_bytes", u64), ("n_prims", u32),
-                ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4)]
+                ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4), ("subtree_ops", u32 * 2)]
 
 
 class PresetOptions(C.Structure):

@@ -1410,6 +1410,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         const bool subtree = code == OP_SUBTREE || code == OP_SUBTREE_SIMPLE;
         ctx->has_subtrees |= subtree;
         ctx->has_general_subtrees |= code == OP_SUBTREE;
+        if (subtree) ctx->info.subtree_ops[code == OP_SUBTREE ? 1 : 0]++;
         ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
         // (the fused ops count as the ops they stand for)
         if (code == OP_MED_SPHERE) top_ops += 5u;

@@ -105,6 +105,41 @@ def test_culling_and_visit_skipping_never_change_a_hit(gpu_ctx, name, kw):
     compare_hits(got, want, exact_t=(name != "final"))
 
 
+@pytest.mark.parametrize("name", ["spheres", "suzanne"])
+def test_bvh_whose_root_box_does_not_hold_the_boxes_below(gpu_ctx, name):
+    """The moves for simple subtrees form the margin of their culling test from the root's box, which must then hold every box
+    below it.  A tree whose boxes do not nest (a caller may hand over any boxes) goes to the general machine, and either way
+    the hits are the oracle's: here every box below the roots is grown past its root's, which lets more rays in and changes
+    no hit the reference's own traversal of those boxes would not change."""
+    b, flat, _ = config_scene(name)
+    simple = gpu_ctx.upload(flat)["subtree_ops"]
+    assert simple[0] >= 1 and simple[1] == 0
+    nodes = flat.bvh_nodes
+    children = set()
+    for i in range(flat.n_bvh_nodes):
+        for r in (nodes[i].left, nodes[i].right):
+            if (r >> 28) == abi.TAG_BVH:
+                children.add(r & ((1 << 28) - 1))
+    saved = [(i, nodes[i].bmin[1], nodes[i].bmax[1]) for i in sorted(children)[:7]]
+    try:
+        for i, lo, hi in saved:
+            nodes[i].bmin[1], nodes[i].bmax[1] = lo - 5000.0, hi + 5000.0
+        info = gpu_ctx.upload(flat)
+        assert info["subtree_ops"][0] < simple[0] and info["subtree_ops"][1] >= 1
+        rays = _stress_rays(flat, 100_000, seed=21)
+        got, want = gpu_ctx.primary_hits(rays, seed=4), O.primary_hits(flat, rays, seed=4)
+        assert np.array_equal(got["prim_id"], want["prim_id"])
+        compare_hits(got, want, exact_t=True)
+        assert (want["prim_id"] >= 0).mean() > 0.05
+        kw = dict(n_slices=2, max_depth=12, seed=5)
+        ref = gpu_ctx.render(device.make_params(48, 40, 8, flags=abi.FLAG_COUNTERS, **kw))["slice_sums"]  # every visit, in the reference's order
+        for flags in (0, abi.FLAG_PATHS, abi.FLAG_WAVEFRONT):
+            assert np.array_equal(gpu_ctx.render(device.make_params(48, 40, 8, flags=flags, **kw))["slice_sums"], ref, equal_nan=True), flags
+    finally:
+        for i, lo, hi in saved:
+            nodes[i].bmin[1], nodes[i].bmax[1] = lo, hi
+
+
 def _random_scene(seed):
     """A scene thrown together from every kind of geometry, in nested BVHs, instances and lists, with the
     awkward cases in: tiny and huge and negative radii, degenerate triangles, flat boxes, a medium in a BVH,
