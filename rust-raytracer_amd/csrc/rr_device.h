@@ -110,6 +110,8 @@ struct DevScene {  // kernel argument
     uint32_t n_ops;                 // ops before the terminating OP_ENDs
     float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
     uint32_t intended;              // RR_SEMANTICS_INTENDED: the labelled alternative semantics (see include/rr_hip.h), 0 by default
+    uint32_t no_tri;                // 0 from the host; a kernel that is only launched for scenes without triangles sets it to 1 in its
+                                    // own copy, and the triangle code (and the registers it needs) is gone from that build
     const RR_CONST_AS DevConst* k;
 };
 
@@ -639,7 +641,7 @@ __device__ __forceinline__ void trav_leaf_simple(const DevScene& sc, Trav& m, Co
             if (COUNT) cnt.sphere_tests++;
             float t;
             if (test_sphere(mk3(q0.x, q0.y, q0.z), q0.w, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, m.cur = node, m.hitf = true;
-        } else if (tag == RR_TAG_TRIANGLE) {
+        } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
             if (COUNT) cnt.tri_tests++;
             float t;
             if (test_triangle(q0, q1, q2, m.o, m.d, m.tmin, m.tmax, sc.intended != 0u, t)) m.tmax = t, m.cur = node, m.hitf = true;
@@ -714,7 +716,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
                 m.cur = node;
                 m.hitf = true;
             }
-        } else if (tag == RR_TAG_TRIANGLE) {
+        } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
             if (COUNT) cnt.tri_tests++;
             float t;
             if (test_triangle(q0, q1, q2, m.o, m.d, m.tmin, m.tmax, sc.intended != 0u, t)) {
@@ -958,7 +960,7 @@ __device__ __forceinline__ void eval_leaf(const DevScene& sc, uint32_t n, f3 o, 
             tmax = t;
             cur = n;
         }
-    } else if (tag == RR_TAG_TRIANGLE) {
+    } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
         if (COUNT) cnt.tri_tests++;
         float t;
         if (test_triangle(sc.tri[3 * idx], sc.tri[3 * idx + 1], sc.tri[3 * idx + 2], o, d, tmin, tmax, sc.intended != 0u, t)) {
@@ -1484,7 +1486,7 @@ __device__ __forceinline__ HitMeta hit_meta(const DevScene& sc, uint32_t ref) {
     } else if (tag == RR_TAG_RECT) {
         const float4 v = sc.rect[2 * idx + 1];
         m.mat = __float_as_uint(v.z), m.owner = __float_as_uint(v.w);
-    } else if (tag == RR_TAG_TRIANGLE) {
+    } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
         const uint2 v = sc.k->tri_meta[idx];
         m.mat = v.x, m.owner = v.y;
     } else if (tag == RR_TAG_MOVING_SPHERE) {
@@ -1515,7 +1517,7 @@ __device__ __forceinline__ HitFetch hit_fetch(const DevScene& sc, uint32_t ref) 
         f.r0 = sc.rect[2 * idx];
         f.r1 = sc.rect[2 * idx + 1];
         f.meta.mat = __float_as_uint(f.r1.z), f.meta.owner = __float_as_uint(f.r1.w);
-    } else if (tag == RR_TAG_TRIANGLE) {
+    } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
         const uint2 v = sc.k->tri_meta[idx];
         f.r0 = sc.tri[3 * idx + 2];
         f.meta.mat = v.x, f.meta.owner = v.y;
@@ -1597,7 +1599,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
         }
         h.front = dot3(d, outn) < 0.0f;
         h.n = h.front ? outn : neg3(outn);
-    } else if (tag == RR_TAG_TRIANGLE) {
+    } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
         const f3 outn = mk3(r0.y, r0.z, r0.w);
         h.front = dot3(d, outn) < 0.0f;
         h.n = h.front ? outn : neg3(outn);
@@ -1625,7 +1627,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     } else if (tag == RR_TAG_RECT) {
         r0 = sc.rect[2 * idx];
         r1 = sc.rect[2 * idx + 1];
-    } else if (tag == RR_TAG_TRIANGLE) {
+    } else if (tag == RR_TAG_TRIANGLE && !sc.no_tri) {
         r0 = sc.tri[3 * idx + 2];
     } else if (tag == RR_TAG_MOVING_SPHERE) {
         r0 = sc.msphere[3 * idx + 2];

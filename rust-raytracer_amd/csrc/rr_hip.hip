@@ -1424,6 +1424,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4;
     ctx->root = to_dref(s->root);
     ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
+    ctx->sc.no_tri = 0u;
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
     ctx->info.wavefront = ctx->auto_pipeline ? 1u : 0u;

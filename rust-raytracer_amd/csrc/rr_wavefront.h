@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
+    sc.no_tri = (WAVES > RR_RENDER_WAVES_PER_SIMD) ? 1u : 0u;  // (the host launches the builds with more waves for scenes without triangles only)
     if (PARK) own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
@@ -286,6 +287,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                   unsigned long long* counters) {
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
+    sc.no_tri = 0u;
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     constexpr uint32_t stride = WF_BLOCK;
@@ -488,6 +490,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                                                                                 WfCtl* ctl, unsigned long long* counters) {
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
+    sc.no_tri = 0u;
     own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
