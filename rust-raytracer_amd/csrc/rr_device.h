@@ -110,6 +110,9 @@ struct DevScene {  // kernel argument
     uint32_t n_ops;                 // ops before the terminating OP_ENDs
     float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
     uint32_t intended;              // RR_SEMANTICS_INTENDED: the labelled alternative semantics (see include/rr_hip.h), 0 by default
+    uint32_t lean;                  // like no_tri: 1 in the kernels the host launches only for scenes whose media are all bounded by a
+                                    // bare sphere (no OP_MED_BEGIN / MID / END), whose cuboids are all the constructor's and whose
+                                    // instances nest at most two deep
     uint32_t no_tri;                // 0 from the host; a kernel that is only launched for scenes without triangles sets it to 1 in its
                                     // own copy, and the triangle code (and the registers it needs) is gone from that build
     const RR_CONST_AS DevConst* k;
@@ -652,7 +655,7 @@ __device__ __forceinline__ void trav_leaf_simple(const DevScene& sc, Trav& m, Co
         } else {  // RR_TAG_CUBOID: six rects as a linear closest-hit list (collider.rs:428-430 -> 751-772)
             const uint32_t first = __float_as_uint(q0.w);
             if (COUNT) cnt.rect_tests += 6;
-            if (__float_as_uint(q1.w) != 0u) {  // the sides are the constructor's (collider.rs:86-101): all six follow from the corners
+            if (__float_as_uint(q1.w) != 0u || sc.lean) {  // the sides are the constructor's (collider.rs:86-101): all six follow from the corners
                 float t;
                 uint32_t side = NONE;
                 if (test_rect_axis<RR_RECT_XY>(q0.x, q1.x, q0.y, q1.y, q1.z, m.o, m.d, m.tmin, m.tmax, t)) m.tmax = t, side = 0;
@@ -1136,6 +1139,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
 #endif
         } else if (code == OP_MED_SPHERE) {
             medium_in_sphere<COUNT>(op, o, d, tmin, tmax, cur, live, rng, cnt);
+        } else if (sc.lean) {  // (a build for scenes without the three ops below)
         } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
             if (COUNT && live) cnt.inst_visits++;
             m_tmin = tmin, m_tmax = tmax, m_cur = cur;
@@ -1430,6 +1434,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (s.live) eval_leaf<COUNT>(sc, uni(op.ref), s.o, s.d, time, s.tmin, s.tmax, s.cur, pcnt);
             } else if (code == OP_MED_SPHERE) {
                 medium_in_sphere<COUNT>(op, s.o, s.d, s.tmin, s.tmax, s.cur, s.live, rng, pcnt);
+            } else if (sc.lean) {  // (a build for scenes without the three ops below)
             } else if (code == OP_MED_BEGIN) {  // collider.rs:437: first boundary probe over (f32::MIN, f32::MAX)
                 if (COUNT && s.live) pcnt.inst_visits++;
                 s.m_tmin = s.tmin, s.m_tmax = s.tmax, s.m_cur = s.cur;
@@ -1551,7 +1556,7 @@ __device__ __forceinline__ HitRec reconstruct_hit(const DevScene& sc, f3 wo, f3 
     const uint32_t tag = dtag(ref), idx = didx(ref);
     const uint32_t owner = meta.owner;
     // the ray in the primitive's space; the directions inside the two outermost instances are kept for the way back
-    const uint32_t depth = owner_depth(owner);
+    const uint32_t depth = sc.lean ? min(owner_depth(owner), 2u) : owner_depth(owner);  // (lean builds: no primitive lies deeper than two instances)
     const float4* chain = sc.chain_rec + owner_inst(owner) * MAX_CHAIN;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 c0 = (EAGER_CHAIN || depth > 0) ? chain[0] : zero4, c1 = (EAGER_CHAIN || depth > 1) ? chain[1] : zero4;

@@ -326,7 +326,7 @@ struct rr_context {
     // wavefront renderer: whether the scene has BVH subtrees, its root for the traversal machine,
     // and a grow-only workspace (path state, two queues, queue controls) with a pinned word through
     // which the host reads the live-path count when it has to (RR_FLAG_NO_FINISH_KERNEL)
-    bool has_triangles = false;  // the scene holds triangles (their test needs more registers than any other)
+    bool lean_scene = false;  // no triangles (their test needs more registers than any other), no OP_MED_BEGIN / MID / END in the program, every cuboid the constructor's, instances at most two deep
     bool has_subtrees = false;
     bool has_general_subtrees = false;  // OP_SUBTREE ops: subtrees the simple machine moves do not cover
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
@@ -1002,7 +1002,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and at 5 waves per SIMD
     // instead of 4 for scenes without triangles (see k_wf_paths).
     constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
-    const bool ref_sem = ctx->sc.intended == 0u, w5 = !ctx->has_triangles;
+    const bool ref_sem = ctx->sc.intended == 0u, w5 = ctx->lean_scene;
     PathsKernel kernel;
     if (ctx->has_subtrees) {
         if (count == COUNT_PRODUCTION) kernel = k_wf_paths<COUNT_PRODUCTION, true, true>;
@@ -1263,12 +1263,14 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         ctx->id_tri[i] = p.prim_id;
     }
     std::vector<float4> cuboid(static_cast<size_t>(s->n_cuboids) * 2 + PAD);
+    bool all_canonical = true;
     for (uint32_t i = 0; i < s->n_cuboids; ++i) {
         // Corners of the box, if the six rects are exactly what Cuboid::new (collider.rs:419-426)
         // makes of two corners; the machine then tests the sides from these 32 bytes alone.
         if (!wk.seen[RR_TAG_CUBOID][i]) continue;  // not part of the tree: never visited, range never checked
         float p0[3], p1[3];
         const bool canonical = cuboid_corners(*s, i, p0, p1);
+        all_canonical &= canonical;
         cuboid[2 * i] = make_float4(p0[0], p0[1], p0[2], u2f(s->cuboids[i].first_rect));
         cuboid[2 * i + 1] = make_float4(p1[0], p1[1], p1[2], u2f(canonical ? 1u : 0u));
     }
@@ -1400,7 +1402,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.max_inst_depth = wk.max_inst_depth;
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
-    ctx->has_triangles = s->n_triangles != 0;
+    ctx->lean_scene = s->n_triangles == 0 && all_canonical && wk.max_inst_depth <= 2;
     ctx->has_subtrees = false;
     ctx->has_general_subtrees = false;
     ctx->prog_vector_ops = false;
@@ -1411,6 +1413,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         ctx->has_subtrees |= subtree;
         ctx->has_general_subtrees |= code == OP_SUBTREE;
         if (subtree) ctx->info.subtree_ops[code == OP_SUBTREE ? 1 : 0]++;
+        if (code == OP_MED_BEGIN || code == OP_MED_MID || code == OP_MED_END) ctx->lean_scene = false;
         ctx->prog_vector_ops |= subtree || code == OP_LEAF_REF;
         // (the fused ops count as the ops they stand for)
         if (code == OP_MED_SPHERE) top_ops += 5u;
@@ -1424,7 +1427,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4;
     ctx->root = to_dref(s->root);
     ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
-    ctx->sc.no_tri = 0u;
+    ctx->sc.no_tri = ctx->sc.lean = 0u;
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by
     ctx->info.wavefront = ctx->auto_pipeline ? 1u : 0u;

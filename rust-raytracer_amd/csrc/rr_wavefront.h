@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
-    sc.no_tri = (WAVES > RR_RENDER_WAVES_PER_SIMD) ? 1u : 0u;  // (the host launches the builds with more waves for scenes without triangles only)
+    // (the host launches the builds with more waves only for scenes without triangles, without media that are not bounded by a
+    // bare sphere and without cuboids that are not the constructor's: that code, and the registers it needs, is not in them)
+    sc.no_tri = sc.lean = (WAVES > RR_RENDER_WAVES_PER_SIMD) ? 1u : 0u;
     if (PARK) own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                   unsigned long long* counters) {
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
-    sc.no_tri = 0u;
+    sc.no_tri = sc.lean = 0u;
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
     constexpr uint32_t stride = WF_BLOCK;
@@ -490,7 +492,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                                                                                 WfCtl* ctl, unsigned long long* counters) {
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
-    sc.no_tri = 0u;
+    sc.no_tri = sc.lean = 0u;
     own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
