@@ -999,8 +999,8 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     st.thr = values;
     using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
     // (a scene without BVH nodes has no visits to skip: its two counting modes are one kernel)
-    // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and at 5 waves per SIMD
-    // instead of 4 for scenes without triangles (see k_wf_paths).
+    // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and for lean scenes
+    // (rr_context::lean_scene) the builds at 5 waves per SIMD instead of 4 that leave out what such scenes do not need (see k_wf_paths).
     constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
     const bool ref_sem = ctx->sc.intended == 0u, w5 = ctx->lean_scene;
     PathsKernel kernel;
@@ -1013,7 +1013,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     } else if (ctx->prog_vector_ops) {
         kernel = count ? k_wf_paths<COUNT_REFERENCE, true> : w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5> : k_wf_paths<COUNT_OFF, true>;
     } else {
-        kernel = count ? k_wf_paths<COUNT_REFERENCE, false> : k_wf_paths<COUNT_OFF, false, false, true, false, W5>;
+        kernel = count ? k_wf_paths<COUNT_REFERENCE, false> : w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5> : k_wf_paths<COUNT_OFF, false>;
     }
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + (ctx->has_subtrees ? 4u * PARK_LDS_WORDS_PER_WAVE * 4u : 0u);
