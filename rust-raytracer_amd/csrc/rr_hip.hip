@@ -326,7 +326,8 @@ struct rr_context {
     // wavefront renderer: whether the scene has BVH subtrees, its root for the traversal machine,
     // and a grow-only workspace (path state, two queues, queue controls) with a pinned word through
     // which the host reads the live-path count when it has to (RR_FLAG_NO_FINISH_KERNEL)
-    bool lean_scene = false;  // no triangles (their test needs more registers than any other), no OP_MED_BEGIN / MID / END in the program, every cuboid the constructor's, instances at most two deep
+    bool has_triangles = false;  // (their test needs more registers than any other)
+    bool lean_scene = false;  // no OP_MED_BEGIN / MID / END in the program, every cuboid the constructor's, instances at most two deep
     bool has_subtrees = false;
     bool has_general_subtrees = false;  // OP_SUBTREE ops: subtrees the simple machine moves do not cover
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
@@ -1002,18 +1003,22 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and for lean scenes
     // (rr_context::lean_scene) the builds at 5 waves per SIMD instead of 4 that leave out what such scenes do not need (see k_wf_paths).
     constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
-    const bool ref_sem = ctx->sc.intended == 0u, w5 = ctx->lean_scene;
+    const bool ref_sem = ctx->sc.intended == 0u, w5 = ctx->lean_scene && !ctx->has_triangles;
     PathsKernel kernel;
     if (ctx->has_subtrees) {
         if (count == COUNT_PRODUCTION) kernel = k_wf_paths<COUNT_PRODUCTION, true, true>;
         else if (count == COUNT_REFERENCE) kernel = k_wf_paths<COUNT_REFERENCE, true, true>;
         else if (!ref_sem) kernel = ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true> : k_wf_paths<COUNT_OFF, true, true, false>;
-        else if (ctx->has_general_subtrees) kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, true, true, W5> : k_wf_paths<COUNT_OFF, true, true, true, true>;
-        else kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5> : k_wf_paths<COUNT_OFF, true, true, false, true>;
+        else if (ctx->has_general_subtrees)
+            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, true, true>;
+        else
+            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true>;
+        // (a lean build at 4 waves for lean scenes with triangles measured no different from the general one: where nothing
+        // is spilled, code that is not run costs nothing)
     } else if (ctx->prog_vector_ops) {
-        kernel = count ? k_wf_paths<COUNT_REFERENCE, true> : w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5> : k_wf_paths<COUNT_OFF, true>;
+        kernel = count ? k_wf_paths<COUNT_REFERENCE, true> : w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, true>;
     } else {
-        kernel = count ? k_wf_paths<COUNT_REFERENCE, false> : w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5> : k_wf_paths<COUNT_OFF, false>;
+        kernel = count ? k_wf_paths<COUNT_REFERENCE, false> : w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, false>;
     }
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + (ctx->has_subtrees ? 4u * PARK_LDS_WORDS_PER_WAVE * 4u : 0u);
@@ -1402,7 +1407,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.max_inst_depth = wk.max_inst_depth;
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
-    ctx->lean_scene = s->n_triangles == 0 && all_canonical && wk.max_inst_depth <= 2;
+    ctx->has_triangles = s->n_triangles != 0;
+    ctx->lean_scene = all_canonical && wk.max_inst_depth <= 2;
     ctx->has_subtrees = false;
     ctx->has_general_subtrees = false;
     ctx->prog_vector_ops = false;

@@ -145,16 +145,20 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // no longer paired f32 operations (which had cost registers): 5 is +9.5 % on the Cornell box and +3.3 % on final_scene,
 // -2 % on Suzanne (the triangle test is what needs the registers), 6 is worse everywhere: the host picks 5 for scenes
 // without triangles.
-template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD>
+// LEAN: a build for lean scenes (rr_context::lean_scene) without the code they do not need; with WAVES above the default it
+// is for lean scenes without triangles and has no triangle code either.
+template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD, bool LEAN = false>
 __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     // REF_SEM: a build that is only launched for scenes with the reference's own semantics, so that the switch is a constant
     // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
     DevScene sc = sc_arg;
     if (REF_SEM) sc.intended = 0u;
-    // (the host launches the builds with more waves only for scenes without triangles, without media that are not bounded by a
-    // bare sphere and without cuboids that are not the constructor's: that code, and the registers it needs, is not in them)
-    sc.no_tri = sc.lean = (WAVES > RR_RENDER_WAVES_PER_SIMD) ? 1u : 0u;
+    // (the host launches the lean builds only for scenes without media that are not bounded by a bare sphere, without cuboids
+    // that are not the constructor's and with instances at most two deep, and those with more waves only if the scene has no
+    // triangles either: that code, and the registers it needs, is not in them)
+    sc.lean = LEAN ? 1u : 0u;
+    sc.no_tri = (LEAN && WAVES > RR_RENDER_WAVES_PER_SIMD) ? 1u : 0u;
     if (PARK) own_registers(sc);
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
