@@ -1221,35 +1221,58 @@ struct ParkArea {        // wave-uniform
         free_mask = (1u << PARK_SLOTS) - 1u;
     }
 };
-__device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, const ProgState& s, const Trav& m) {
+// `open_medium`: the program can be between OP_MED_BEGIN and OP_MED_END at a subtree; false in the lean builds, whose programs
+// have no such ops: the four words of the open medium are then neither saved nor loaded.
+// `simple`: the visit is of a simple subtree, inside which the machine's ray and t_min are the program's at that op (nothing
+// below changes the ray space or the range's lower end): they are saved once, and after a load the machine's are the
+// program's *registers*, not copies the compiler must keep beside them through the loop of the machine.
+__device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, const ProgState& s, const Trav& m, bool open_medium, bool simple) {
     uint32_t* w = pa.slots + slot;
-    const float v[18] = {m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, m.tmin, m.tmax, s.o.x, s.o.y, s.o.z, s.d.x, s.d.y, s.d.z, s.tmin, s.m_tmin, s.m_tmax, s.m_t1};
+    if (!simple) {
+        const float v[7] = {m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, m.tmin};
 #pragma unroll
-    for (uint32_t k = 0; k < 18; ++k) w[k * PARK_SLOTS] = __float_as_uint(v[k]);
+        for (uint32_t k = 0; k < 7; ++k) w[k * PARK_SLOTS] = __float_as_uint(v[k]);
+    }
+    const float v[8] = {m.tmax, s.o.x, s.o.y, s.o.z, s.d.x, s.d.y, s.d.z, s.tmin};
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) w[(7 + k) * PARK_SLOTS] = __float_as_uint(v[k]);
+    if (open_medium) {
+        w[15 * PARK_SLOTS] = __float_as_uint(s.m_tmin), w[16 * PARK_SLOTS] = __float_as_uint(s.m_tmax), w[17 * PARK_SLOTS] = __float_as_uint(s.m_t1);
+        w[21 * PARK_SLOTS] = s.m_cur;
+    }
     w[18 * PARK_SLOTS] = m.cur;
     w[19 * PARK_SLOTS] = m.node;
     w[20 * PARK_SLOTS] = m.sp | (m.hitf ? 1u << 31 : 0u) | (s.live ? 1u << 30 : 0u);
-    w[21 * PARK_SLOTS] = s.m_cur;
 }
-__device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, ProgState& s, Trav& m) {
+__device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, ProgState& s, Trav& m, bool open_medium, bool simple) {
     const uint32_t* w = pa.slots + slot;
-    float v[18];
+    float v[8];
 #pragma unroll
-    for (uint32_t k = 0; k < 18; ++k) v[k] = __uint_as_float(w[k * PARK_SLOTS]);
-    m.set_ray(mk3(v[0], v[1], v[2]), mk3(v[3], v[4], v[5]));  // (1/direction and the culling flag follow from the ray)
-    m.tmin = v[6], m.tmax = v[7];
-    s.o = mk3(v[8], v[9], v[10]), s.d = mk3(v[11], v[12], v[13]);
-    s.tmin = v[14], s.m_tmin = v[15], s.m_tmax = v[16], s.m_t1 = v[17];
+    for (uint32_t k = 0; k < 8; ++k) v[k] = __uint_as_float(w[(7 + k) * PARK_SLOTS]);
+    m.tmax = v[0];
+    s.o = mk3(v[1], v[2], v[3]), s.d = mk3(v[4], v[5], v[6]);
+    s.tmin = v[7];
+    if (!simple) {  // (simple: the caller makes the program's ray and t_min the machine's, for every lane alike)
+        float u[7];
+#pragma unroll
+        for (uint32_t k = 0; k < 7; ++k) u[k] = __uint_as_float(w[k * PARK_SLOTS]);
+        m.set_ray(mk3(u[0], u[1], u[2]), mk3(u[3], u[4], u[5]));  // (1/direction and the culling flag follow from the ray)
+        m.tmin = u[6];
+    }
+    if (open_medium) {
+        s.m_tmin = __uint_as_float(w[15 * PARK_SLOTS]), s.m_tmax = __uint_as_float(w[16 * PARK_SLOTS]), s.m_t1 = __uint_as_float(w[17 * PARK_SLOTS]);
+        s.m_cur = w[21 * PARK_SLOTS];
+    }
     m.cur = w[18 * PARK_SLOTS];
     m.node = w[19 * PARK_SLOTS];
     const uint32_t f = w[20 * PARK_SLOTS];
     m.sp = f & 0xFFFFu, m.hitf = (f >> 31) != 0u, s.live = ((f >> 30) & 1u) != 0u;
-    s.m_cur = w[21 * PARK_SLOTS];
 }
 
 // After a visit of a subtree: lanes whose descent is complete take its result and give their slot back; the others
 // are parked at `this_pc`, in the slot they have or in a free one.  Wave-uniform control flow.
-__device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Trav& m, uint32_t& slot, bool in, uint32_t this_pc, bool& act) {
+__device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Trav& m, uint32_t& slot, bool in, uint32_t this_pc, bool& act,
+                                            bool open_medium, bool simple) {
     const bool done = in && m.finished();
     uint64_t fm = RR_BALLOT(done && s.parked);  // slots coming back
     while (fm != 0) {
@@ -1275,7 +1298,7 @@ __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Tr
             s.parked = true;
             s.park_pc = this_pc;
             act = false;
-            park_save(pa, slot, s, m);
+            park_save(pa, slot, s, m, open_medium, simple);
         }
     }
 }
@@ -1328,7 +1351,10 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
             Trav m;
             m.begin(NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
-            if (rejoin) park_load(pa, slot, s, m);
+            if (rejoin) park_load(pa, slot, s, m, sc.lean == 0u, true);
+            if (sc.lean) s.tmin = tmin0, s.live = true;  // (only the medium ops a lean program does not have change them: constants, not registers)
+            m.set_ray(s.o, s.d);  // (the lanes that rejoin have their ray from their slot: one set of registers for the program's ray and the machine's)
+            m.tmin = s.tmin;
 #ifndef RR_NODE_MARGIN
             constexpr bool SUBTREE_MARGIN = true;
             m.margin = cull_margin(sc, m.o, mk3(op.f0, op.f1, op.f2), mk3(op.f3, op.f4, op.f5));
@@ -1372,7 +1398,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
-            park_settle(pa, s, m, slot, in, this_pc, act);
+            park_settle(pa, s, m, slot, in, this_pc, act, sc.lean == 0u, true);
         } else if (code == OP_SUBTREE) {
 #ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             continue;
@@ -1382,7 +1408,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             const bool enter = act && s.live;
             Trav m;
             m.begin(enter ? uni(op.ref) : NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
-            if (rejoin) park_load(pa, slot, s, m);
+            if (rejoin) park_load(pa, slot, s, m, sc.lean == 0u, false);
+            if (sc.lean) s.tmin = tmin0, s.live = true;
             const bool in = enter || rejoin;
             uint32_t steps = 0;
             for (;;) {
@@ -1393,7 +1420,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
             }
-            park_settle(pa, s, m, slot, in, this_pc, act);
+            park_settle(pa, s, m, slot, in, this_pc, act, sc.lean == 0u, false);
         } else if (act) {
             if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
                 if (COUNT && s.live) pcnt.rect_tests++;
