@@ -1012,9 +1012,9 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
         else if (ctx->has_general_subtrees)
             kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, true, true>;
         else
-            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true>;
-        // (a lean build at 4 waves for lean scenes with triangles measured no different from the general one: where nothing
-        // is spilled, code that is not run costs nothing)
+            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true, W5, false>;
+        // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
+        // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
     } else if (ctx->prog_vector_ops) {
         kernel = count ? k_wf_paths<COUNT_REFERENCE, true> : w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, true>;
     } else {

@@ -141,10 +141,10 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // at very different times (measured on the Cornell box, 125 samples per item, 11 items per lane: 10 % of the run).
 // A wave claims RR_PATHS_CHUNK consecutive paths with one atomic (64 lanes next to each other in an image row) and
 // hands them to its lanes as their paths end.
-// WAVES: waves per SIMD the register allocator leaves room for (4: 128 vector registers, 5: 102).  Measured once the build
-// no longer paired f32 operations (which had cost registers): 5 is +9.5 % on the Cornell box and +3.3 % on final_scene,
-// -2 % on Suzanne (the triangle test is what needs the registers), 6 is worse everywhere: the host picks 5 for scenes
-// without triangles.
+// WAVES: waves per SIMD the register allocator leaves room for (4: 128 vector registers, 5: 96).  Measured once the build
+// no longer paired f32 operations (which had cost registers): 5 is +9.5 % on the Cornell box and +3.3 % on final_scene, and,
+// once parked lanes no longer held a second copy of their ray, +4 % on Suzanne; 6 is worse everywhere (-23 % final_scene,
+// -4 % Cornell box).  The host picks 5 for lean scenes and for scenes whose subtrees are all simple.
 // LEAN: a build for lean scenes (rr_context::lean_scene) without the code they do not need; with WAVES above the default it
 // is for lean scenes without triangles and has no triangle code either.
 template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD, bool LEAN = false>
