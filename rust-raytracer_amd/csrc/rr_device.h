@@ -1334,13 +1334,25 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         if (!(n < park_below && steps >= min_steps)) return false;
         return static_cast<uint32_t>(__popcll(RR_BALLOT(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
-    for (;;) {  // (the counted loop of traverse measured slower here: -1.5 % final_scene, -4.6 % Suzanne; this kernel has no scalar registers to spare)
+#ifndef RR_PARKING_INDEXED_LOOP
+    // A counted loop over a moving pointer, as in traverse.  (Measured slower here while the kernel was short of scalar registers,
+    // -1.5 % final_scene and -4.6 % Suzanne; once own_registers and the Philox round keys had given scalar registers back: +1.7 % and +5.6 %.)
+    const uint32_t n_ops = uni(sc.n_ops);
+    for (; pc != n_ops; ++pc) {
+        const Op op = next;
+        const uint32_t this_pc = pc;
+        ++prog;
+        next = *prog;
+        const uint32_t code = uni(op.code) & 0xFFu;
+#else
+    for (;;) {
         const Op op = next;
         const uint32_t this_pc = pc;
         pc = uni(pc + 1);
         next = prog[pc];
         const uint32_t code = uni(op.code) & 0xFFu;
         if (code == OP_END) break;
+#endif
         if (code == OP_SUBTREE_SIMPLE) {
 #ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             continue;
