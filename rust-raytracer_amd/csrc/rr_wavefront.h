@@ -236,7 +236,8 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             Bounce b;
             HitFetch hf{};
             if (ref != NONE) hf = hit_fetch(sc, ref);
-            go_on = shade<!PARK, true>(sc, ro, rd, time, t, ref, hf.meta, g, b, hf.r0, hf.r1);
+            // (the eager fetch of reconstruct_hit: +1 % in the lean build of final_scene, -0.8 % on Suzanne)
+            go_on = shade<!PARK || LEAN, true>(sc, ro, rd, time, t, ref, hf.meta, g, b, hf.r0, hf.r1);
             if (go_on) {
                 ro = b.o;
                 rd = b.d;
