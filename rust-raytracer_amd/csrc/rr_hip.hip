@@ -1430,7 +1430,10 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // pipeline (pure traversal at twice the occupancy) are the faster way through the camera rays; when the scene
     // program has work of its own, the path-granular persistent kernel is (measured: random spheres 2770 against
     // 2580-2610 Msamples/s, final_scene 1200 against 1155-1175, Cornell box with the Suzanne mesh 2175 against 2800-2830).
-    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4;
+    // (Since the path kernel stopped spilling and went to 5 waves it is also ahead on small all-BVH scenes: random spheres 4630
+    // against 3965 Msamples/s at 1000 spp.  The pipeline keeps the scenes that do not fit the 4 MiB L2 of an XCD, whose
+    // traversal waits for memory: the 1.1 M-primitive mesh 40.9 against 31.2.)
+    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && mem.bytes > (4u << 20);
     ctx->root = to_dref(s->root);
     ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
     ctx->sc.no_tri = ctx->sc.lean = 0u;
