@@ -1431,9 +1431,10 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // program has work of its own, the path-granular persistent kernel is (measured: random spheres 2770 against
     // 2580-2610 Msamples/s, final_scene 1200 against 1155-1175, Cornell box with the Suzanne mesh 2175 against 2800-2830).
     // (Since the path kernel stopped spilling and went to 5 waves it is also ahead on small all-BVH scenes: random spheres 4630
-    // against 3965 Msamples/s at 1000 spp.  The pipeline keeps the scenes that do not fit the 4 MiB L2 of an XCD, whose
-    // traversal waits for memory: the 1.1 M-primitive mesh 40.9 against 31.2.)
-    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && mem.bytes > (4u << 20);
+    // against 3965 Msamples/s at 1000 spp.  The pipeline keeps the larger ones, whose traversal waits for memory: measured on
+    // height fields with spheres of 0.5 / 2 / 5.6 / 20 / 48 / 95 MB (1280x720, 16 spp), path kernel against pipeline: 8.1 / 8.1,
+    // 19.9 / 16.5, 54.6 / 40.8, 156 / 100, 358 / 210 ms, and 31.2 against 40.9 Msamples/s on the 1.1 M-primitive mesh.)
+    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && mem.bytes > (1u << 20);
     ctx->root = to_dref(s->root);
     ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
     ctx->sc.no_tri = ctx->sc.lean = 0u;
