@@ -1031,6 +1031,11 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
         if (a.n_paths != 0) {
             HIP_TRY(hipMemsetAsync(next_path, 0, sizeof(unsigned long long), stream));
             const uint32_t g = std::min<uint32_t>(static_cast<uint32_t>(grid), (a.n_paths + 255u) / 256u);
+#ifndef RR_PATHS_FIXED_CHUNK
+            // Small batches in smaller chunks, so that every wave makes several claims and the waves end together: a sixteenth of
+            // a wave's share, in steps of 64 paths between 64 and RR_PATHS_CHUNK.
+            a.paths_chunk = std::min<uint32_t>(std::max<uint32_t>(a.n_paths / (g * 4u * 16u) / 64u * 64u, 64u), RR_PATHS_CHUNK);
+#endif
             hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, next_path, counters);
             HIP_TRY(hipGetLastError());
         }

@@ -67,6 +67,7 @@ struct WfArgs {
     uint32_t max_depth;
     uint32_t sample_offset;
     uint32_t stack_words;  // words of traversal stack per lane: the wave's slots for parked lanes follow the stacks in LDS
+    uint32_t paths_chunk;  // k_wf_paths: paths a wave claims at a time (0: RR_PATHS_CHUNK)
     uint64_t seed;
 };
 
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     constexpr uint32_t stride = WF_BLOCK;  // word w of a lane's stack is at stk[w * stride]: a shift, not a multiplication by a register
     Counts cnt = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
+    const uint32_t chunk = a.paths_chunk != 0u ? a.paths_chunk : RR_PATHS_CHUNK;
     bool exhausted = a.n_paths == 0;        // wave-uniform: no unclaimed paths are left for anyone
     bool path_active = false;
     uint32_t p = 0, pixel = 0, sample = 0, depth_left = 0, bounce = 0;
@@ -183,10 +185,10 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
         if (!exhausted && idle != 0) {
             if (chunk_pos == chunk_end) {
                 uint32_t base = 0;
-                if ((threadIdx.x & 63u) == 0) base = atomicAdd(next_path, RR_PATHS_CHUNK);
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(next_path, chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
                 chunk_pos = min(base, a.n_paths);
-                chunk_end = min(base + RR_PATHS_CHUNK, a.n_paths);
+                chunk_end = min(base + chunk, a.n_paths);
             }
             const uint32_t take = min(static_cast<uint32_t>(__popcll(idle)), chunk_end - chunk_pos);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
