@@ -140,6 +140,20 @@ def test_bvh_whose_root_box_does_not_hold_the_boxes_below(gpu_ctx, name):
             nodes[i].bmin[1], nodes[i].bmax[1] = lo, hi
 
 
+def test_which_scenes_take_the_wavefront_pipeline(gpu_ctx):
+    """rr_scene_info.wavefront: scenes that are all BVH and larger than 1 MiB go through the wavefront pipeline by default, every
+    other scene through the path kernel; whichever runs, the bits are the other's."""
+    for name, kw, want in [("spheres", {}, False), ("final", {}, False), ("suzanne", {}, False),
+                           ("mesh", dict(n_triangles=60_000, n_spheres=6_000), True)]:
+        b, flat, _ = host.build_config_scene(name, **kw)
+        info = gpu_ctx.upload(flat)
+        assert info["wavefront"] == want, (name, info)
+    p = dict(n_slices=2, max_depth=8, seed=3)
+    auto = gpu_ctx.render(device.make_params(96, 54, 4, **p))["slice_sums"]
+    for flags in (abi.FLAG_PATHS, abi.FLAG_WAVEFRONT):
+        assert np.array_equal(auto, gpu_ctx.render(device.make_params(96, 54, 4, flags=flags, **p))["slice_sums"], equal_nan=True), flags
+
+
 def _random_scene(seed):
     """A scene thrown together from every kind of geometry, in nested BVHs, instances and lists, with the
     awkward cases in: tiny and huge and negative radii, degenerate triangles, flat boxes, a medium in a BVH,
