@@ -306,6 +306,9 @@ typedef struct rr_scene_info {
                                        [3] the same against [0,inf) (triangles below)                              */
     uint32_t subtree_ops[2]; /* BVH subtrees the scene program hands to the per-lane machine: [0] to the moves for BVH nodes over
                                 spheres, rects, triangles and cuboids whose root box holds every box below, [1] to the general machine */
+    uint64_t workspace_bytes; /* device memory the context's render calls have allocated so far (grow-only workspace and work
+                                counter of rr_render_device / rr_render); stays 0 on a context that only ever rendered through
+                                rr_render_device_noalloc                                                                    */
 } rr_scene_info;
 
 typedef struct rr_context rr_context;
@@ -410,8 +413,8 @@ int rr_last_kernel_ms(rr_context* ctx, float* ms);
  * form over torch.distributed / RCCL is rust_raytracer_amd/multi.py): the job is cut into bands of image rows and groups of
  * sample slices (render.rs:130-140 shares out samples; rows share out pixels), every device renders its share on a stream of
  * its own, the images of a band's slice groups are added on the band's first device (peer copies over xGMI where the devices
- * can reach each other, then one add kernel: the mutex sum of render.rs:141-150, in group order), and every band is cast and
- * copied to its rows of the host image.  The scene is replicated.  split:
+ * can reach each other, then one add kernel, or one ncclReduce over RCCL: the mutex sum of render.rs:141-150; see
+ * rr_multi_set_reduce), and every band is cast and copied to its rows of the host image.  The scene is replicated.  split:
  *   RR_SPLIT_SLICES  device g renders slices [g*K/N, (g+1)*K/N) of the whole image;
  *   RR_SPLIT_ROWS    device b renders rows [b*H/N, (b+1)*H/N) with every slice: bit for bit the single-device image;
  *   RR_SPLIT_BOTH    B bands x G groups, B the smallest divisor of N with B*B >= N; device r is band r / G, group r % G.
@@ -427,6 +430,25 @@ int rr_multi_destroy(rr_multi* m);
 int rr_multi_scene_upload(rr_multi* m, const rr_flat_scene* scene);
 int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, uint8_t* out_rgb8,
                     float* out_resolved, float* out_linear, rr_counters* out_counters);
+
+/* How rr_multi_render adds the images of a band's slice groups onto the band's first device (the mutex sum of
+ * render.rs:141-150):
+ *   RR_REDUCE_AUTO  (default) one ncclReduce(sum, f32) per band over RCCL / xGMI when there is more than one slice group, the
+ *                   band's devices are distinct GPUs and librccl.so can be opened (it is opened with dlopen at the first
+ *                   such call, so a one-GPU host needs no RCCL); the peer-copy sum otherwise;
+ *   RR_REDUCE_PEER  hipMemcpyPeerAsync of each group's images to the band's first device and an add kernel there, in
+ *                   group order: the association of the f32 sum is that of a loop over the groups;
+ *   RR_REDUCE_RCCL  RCCL or fail: rr_multi_set_reduce fails with RR_E_NO_DEVICE when librccl.so cannot be opened, and a
+ *                   later rr_multi_render fails when a band lists a device twice or a communicator cannot be made.  Every
+ *                   band goes through ncclReduce, also a band of ONE device (a copy in place).
+ * RCCL chooses the association of the sum (ring or tree order): with two slice groups the image is bit for bit the
+ * peer-copy one (a + b), with more it agrees up to f32 rounding of the sum.
+ * rr_multi_reduce_used reports which of RR_REDUCE_PEER / RR_REDUCE_RCCL the last rr_multi_render used.               */
+#define RR_REDUCE_AUTO 0u
+#define RR_REDUCE_PEER 1u
+#define RR_REDUCE_RCCL 2u
+int rr_multi_set_reduce(rr_multi* m, uint32_t mode);
+int rr_multi_reduce_used(rr_multi* m, uint32_t* mode);
 
 const char* rr_last_error(void);
 

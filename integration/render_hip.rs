@@ -208,8 +208,19 @@ fn check(rc: i32) {
     }
 }
 
+/// render_multi's signature: ONE GPU (device 0), the path every test of the device library exercises.
 pub fn render_hip(scene: SceneColliders, lights: Geometry, cam: Camera, background: Rgb, max_depth: usize, samples_per_pixel: usize,
                   img_width: u32, img_height: u32) -> ImageBuffer<ImgRgb<u8>, Vec<u8>> {
+    render_hip_on(&[0], scene, lights, cam, background, max_depth, samples_per_pixel, img_width, img_height)
+}
+
+/// The same over the listed GPUs of the node (opt-in: the caller names the devices).  More than one device goes through
+/// rr_multi_* (bands of image rows: disjoint pixels, so the image is bit for bit the one-GPU image); if that route cannot be
+/// set up or fails (a listed device that is not a gfx950 GPU, no peer route, ...) the render falls back to the first listed
+/// device alone and says so on stderr.  The list is cut to one device per image row at most.
+pub fn render_hip_on(devices: &[i32], scene: SceneColliders, lights: Geometry, cam: Camera, background: Rgb, max_depth: usize,
+                     samples_per_pixel: usize, img_width: u32, img_height: u32) -> ImageBuffer<ImgRgb<u8>, Vec<u8>> {
+    assert!(!devices.is_empty(), "render_hip_on: no device listed");
     let mut f = Flattener::default();
     let top: Vec<u32> = scene.objects.iter().map(|g| f.geometry(g)).collect(); // depth-first, in order
     let root = f.list(top);
@@ -255,19 +266,24 @@ pub fn render_hip(scene: SceneColliders, lights: Geometry, cam: Camera, backgrou
     let p = rr_render_params { width: img_width, height: img_height, samples_per_pixel: samples_per_pixel as u32, n_slices: k, slice_begin: 0,
                                slice_end: k, max_depth: max_depth as u32, seed: rand::random(), sample_offset: 0, flags: 0, row_begin: 0, row_end: 0 };
     let mut rgb = vec![0u8; (img_width * img_height * 3) as usize];
-    let mut n_devices = 0;
-    check(unsafe { rr_device_count(&mut n_devices) });
-    if n_devices > 1 {
-        // every GPU of the node: bands of image rows (disjoint pixels, so the image is bit for bit the one-GPU image)
-        let devices: Vec<i32> = (0..n_devices).collect();
+    let devices = &devices[..devices.len().min(img_height.max(1) as usize)];
+    let mut done = false;
+    if devices.len() > 1 {
         let mut multi = null_mut();
-        check(unsafe { rr_multi_create(n_devices, devices.as_ptr(), &mut multi) });
-        check(unsafe { rr_multi_scene_upload(multi, &flat) });
-        check(unsafe { rr_multi_render(multi, &p, RR_SPLIT_ROWS, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut()) });
-        unsafe { rr_multi_destroy(multi) };
-    } else {
+        let mut rc = unsafe { rr_multi_create(devices.len() as i32, devices.as_ptr(), &mut multi) };
+        if rc == RR_OK { rc = unsafe { rr_multi_scene_upload(multi, &flat) }; }
+        if rc == RR_OK { rc = unsafe { rr_multi_render(multi, &p, RR_SPLIT_ROWS, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut()) }; }
+        if rc == RR_OK {
+            done = true;
+        } else {
+            let msg = unsafe { CStr::from_ptr(rr_last_error()) }.to_string_lossy().into_owned();
+            eprintln!("render_hip: {} devices failed ({msg}, {rc}); rendering on device {} alone", devices.len(), devices[0]);
+        }
+        if !multi.is_null() { unsafe { rr_multi_destroy(multi) }; }
+    }
+    if !done {
         let mut ctx = null_mut();
-        check(unsafe { rr_context_create(0, &mut ctx) });
+        check(unsafe { rr_context_create(devices[0], &mut ctx) });
         check(unsafe { rr_scene_upload(ctx, &flat) });
         check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
         unsafe { rr_context_destroy(ctx) };

@@ -29,6 +29,7 @@ PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
 EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
 SPLIT_SLICES, SPLIT_ROWS, SPLIT_BOTH = 0, 1, 2
+REDUCE_AUTO, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
 SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
 
 
@@ -153,7 +154,8 @@ class Hit(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("stack_words", u32), ("max_inst_depth", u32), ("device_bytes", u64), ("n_prims", u32),
-                ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4), ("subtree_ops", u32 * 2)]
+                ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4), ("subtree_ops", u32 * 2),
+                ("workspace_bytes", u64)]
 
 
 class PresetOptions(C.Structure):
@@ -188,6 +190,8 @@ HIP_PROTOTYPES = {
     "rr_multi_destroy": (C.c_int, [vp]),
     "rr_multi_scene_upload": (C.c_int, [vp, P(FlatScene)]),
     "rr_multi_render": (C.c_int, [vp, P(RenderParams), u32, P(u8), f3, f3, P(Counters)]),
+    "rr_multi_set_reduce": (C.c_int, [vp, u32]),
+    "rr_multi_reduce_used": (C.c_int, [vp, P(u32)]),
     "rr_last_error": (C.c_char_p, []),
 }
 

@@ -41,6 +41,19 @@ def _headers():
     return [os.path.join(INCLUDE, "rr_hip.h"), os.path.join(INCLUDE, "rr_host.h")]
 
 
+def source_digest():
+    """sha256 over the device sources (csrc/*, sorted by name) and the hipcc flags: names the kernels a measurement was
+    taken on, so that counter summaries kept beside the code can be told from stale ones."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode() + b"\0")
+            h.update(open(os.path.join(CSRC, name), "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def build_hip(force=False):
     src = [os.path.join(CSRC, "rr_hip.hip")]
     deps = src + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + _headers()

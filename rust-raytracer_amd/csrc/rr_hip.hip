@@ -7,11 +7,15 @@
 // moment a path ends, so that all 64 lanes of a wave stay busy whatever the path
 // lengths are.  Lanes of a wave hold the 64 pixels of one 8x8 tile.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // declarations only: librccl.so is opened at run time, the first time a sum over devices asks for it
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1455,6 +1459,7 @@ int rr_scene_info_get(rr_context* ctx, rr_scene_info* out) {
     if (!ctx || !out) return fail(RR_E_INVALID, "rr_scene_info_get: NULL argument");
     if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "no scene uploaded");
     *out = ctx->info;
+    out->workspace_bytes = ctx->wf_bytes + (ctx->next_item ? sizeof(unsigned long long) : 0u);
     return RR_OK;
 }
 
@@ -1759,18 +1764,63 @@ int rr_render(rr_context* ctx, const rr_render_params* p, uint8_t* out_rgb8, flo
 
 
 // ------------------------------------------------------------------ several GPUs from one host thread
+// RCCL, bound at run time: a host with one GPU (or without librccl.so) still loads this library and uses the peer-copy sum.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;  // why it is not usable, when it is not
+    bool ok() const { return handle != nullptr; }
+};
+static Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) {
+            const char* e = dlerror();
+            x.why = std::string("librccl.so not loadable: ") + (e ? e : "?");
+            return x;
+        }
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        x.Reduce = reinterpret_cast<decltype(x.Reduce)>(dlsym(h, "ncclReduce"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!x.CommInitAll || !x.CommDestroy || !x.Reduce || !x.GroupStart || !x.GroupEnd || !x.GetErrorString) {
+            x.why = "librccl.so lacks one of ncclCommInitAll / ncclCommDestroy / ncclReduce / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
+            dlclose(h);
+            return x;
+        }
+        x.handle = h;
+        return x;
+    }();
+    return r;
+}
+
 struct rr_multi {
     struct Dev {
         int device = 0;
         rr_context* ctx = nullptr;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        // resolved and linear are the two halves of ONE allocation (linear = resolved + image), so that a band's slice
+        // groups are summed with one collective over both
         float *sums = nullptr, *resolved = nullptr, *linear = nullptr, *stage = nullptr;
         uint8_t* u8 = nullptr;
         unsigned long long* counters = nullptr;
         size_t sums_bytes = 0, image_bytes = 0;
     };
     std::vector<Dev> devs;
+    uint32_t reduce_mode = RR_REDUCE_AUTO;
+    uint32_t reduce_used = RR_REDUCE_PEER;  // what the last rr_multi_render summed its slice groups with
+    std::map<uint32_t, std::vector<ncclComm_t>> comms;  // by number of slice groups G: one communicator per device, band b's are [b*G, (b+1)*G)
 };
 
 namespace {
@@ -1788,6 +1838,58 @@ int grow(void** p, size_t* have, size_t need) {
     return RR_OK;
 }
 }  // namespace
+
+namespace {
+// Which way the slice groups of every band are summed in this call, and the communicators for it.
+// AUTO: RCCL when there is something to sum (G > 1), every band's devices are distinct GPUs (a communicator cannot hold one
+// device twice) and librccl.so loads and initialises; the peer-copy sum otherwise.  RCCL (forced): every band goes through
+// ncclReduce, also a band of one device, where the reduce is a copy in place: an error if RCCL cannot be used.
+int pick_reduce(rr_multi* m, uint32_t bands, uint32_t groups, bool* use_rccl) {
+    *use_rccl = false;
+    if (m->reduce_mode == RR_REDUCE_PEER) return RR_OK;
+    const bool forced = m->reduce_mode == RR_REDUCE_RCCL;
+    if (!forced && groups < 2) return RR_OK;
+    for (uint32_t b = 0; b < bands; ++b) {
+        std::set<int> seen;
+        for (uint32_t g = 0; g < groups; ++g)
+            if (!seen.insert(m->devs[b * groups + g].device).second)
+                return forced ? fail(RR_E_INVALID, "rr_multi_render: RR_REDUCE_RCCL needs distinct devices within a band (a communicator cannot hold a device twice)") : RR_OK;
+    }
+    Rccl& R = rccl();
+    if (!R.ok()) return forced ? fail(RR_E_NO_DEVICE, "rr_multi_render: " + R.why) : RR_OK;
+    if (!m->comms.count(groups)) {
+        std::vector<ncclComm_t> comms(m->devs.size(), nullptr);
+        for (uint32_t b = 0; b < bands; ++b) {
+            std::vector<int> list;
+            for (uint32_t g = 0; g < groups; ++g) list.push_back(m->devs[b * groups + g].device);
+            const ncclResult_t nr = R.CommInitAll(&comms[b * groups], static_cast<int>(groups), list.data());
+            if (nr != ncclSuccess) {
+                for (ncclComm_t c : comms)
+                    if (c) (void)R.CommDestroy(c);
+                if (forced) return fail(RR_E_HIP, std::string("rr_multi_render: ncclCommInitAll failed: ") + R.GetErrorString(nr));
+                m->reduce_mode = RR_REDUCE_PEER;  // do not try again at every call
+                return RR_OK;
+            }
+        }
+        m->comms[groups] = comms;
+    }
+    *use_rccl = true;
+    return RR_OK;
+}
+}  // namespace
+
+int rr_multi_set_reduce(rr_multi* m, uint32_t mode) {
+    if (!m || mode > RR_REDUCE_RCCL) return fail(RR_E_INVALID, "rr_multi_set_reduce: bad argument");
+    if (mode == RR_REDUCE_RCCL && !rccl().ok()) return fail(RR_E_NO_DEVICE, "rr_multi_set_reduce: " + rccl().why);
+    m->reduce_mode = mode;
+    return RR_OK;
+}
+
+int rr_multi_reduce_used(rr_multi* m, uint32_t* mode) {
+    if (!m || !mode) return fail(RR_E_INVALID, "rr_multi_reduce_used: NULL argument");
+    *mode = m->reduce_used;
+    return RR_OK;
+}
 
 int rr_multi_create(int n_devices, const int* devices, rr_multi** out) {
     if (!out || n_devices < 1 || !devices) return fail(RR_E_INVALID, "rr_multi_create: bad argument");
@@ -1826,12 +1928,21 @@ int rr_multi_create(int n_devices, const int* devices, rr_multi** out) {
 
 int rr_multi_destroy(rr_multi* m) {
     if (!m) return RR_OK;
+    for (rr_multi::Dev& d : m->devs)
+        if (d.ctx && d.stream) {
+            (void)hipSetDevice(d.device);
+            (void)hipStreamSynchronize(d.stream);
+        }
+    for (auto& kv : m->comms)
+        for (ncclComm_t c : kv.second)
+            if (c) (void)rccl().CommDestroy(c);
+    m->comms.clear();
     for (rr_multi::Dev& d : m->devs) {
         if (!d.ctx) continue;  // creation stopped before this entry (its device may not even exist)
         (void)hipSetDevice(d.device);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
-        for (void* p : {static_cast<void*>(d.sums), static_cast<void*>(d.resolved), static_cast<void*>(d.linear), static_cast<void*>(d.stage),
-                        static_cast<void*>(d.u8), static_cast<void*>(d.counters)})
+        for (void* p : {static_cast<void*>(d.sums), static_cast<void*>(d.resolved), static_cast<void*>(d.stage),
+                        static_cast<void*>(d.u8), static_cast<void*>(d.counters)})  // (d.linear is the second half of d.resolved)
             if (p) (void)hipFree(p);
         if (d.done) (void)hipEventDestroy(d.done);
         if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -1878,34 +1989,51 @@ int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, ui
         size_t keep = d.image_bytes;
         if (int rc = grow(reinterpret_cast<void**>(&d.sums), &d.sums_bytes, image * std::max(n_sl, 1u))) return rc;
         if (image > d.image_bytes || !d.resolved) {
-            for (float** q : {&d.resolved, &d.linear, &d.stage}) {
-                size_t have = keep;
-                if (int rc = grow(reinterpret_cast<void**>(q), &have, image)) return rc;
-            }
+            size_t have = keep * 2u;
+            if (int rc = grow(reinterpret_cast<void**>(&d.resolved), &have, image * 2u)) return rc;
+            have = keep * 2u;
+            if (int rc = grow(reinterpret_cast<void**>(&d.stage), &have, image * 2u)) return rc;
             size_t have8 = keep / 4u;
             if (int rc = grow(reinterpret_cast<void**>(&d.u8), &have8, image / 4u)) return rc;
             d.image_bytes = image;
         }
+        d.linear = d.resolved + image / sizeof(float);  // the band's two images back to back, whatever the band's size
         HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(rr_counters), d.stream));
         if (int rc = rr_render_device(d.ctx, &p, d.sums, d.resolved, d.linear, d.counters, d.stream)) return rc;
         HIP_TRY(hipEventRecord(d.done, d.stream));
     }
     // ---- per band: the slice groups' images are added onto the band's first device, in group order (the mutex sum of
     // render.rs:141-150), then cast (render.rs:156-159) and copied to their rows of the host image
+    bool use_rccl = false;
+    if (int rc = pick_reduce(m, bands, groups, &use_rccl)) return rc;
+    m->reduce_used = use_rccl ? RR_REDUCE_RCCL : RR_REDUCE_PEER;
     for (uint32_t b = 0; b < bands; ++b) {
         rr_multi::Dev& root = m->devs[b * groups];
         const rr_render_params& p = share[b * groups];
         const uint64_t n = static_cast<uint64_t>(W) * (p.row_end - p.row_begin) * 3u;
-        HIP_TRY(hipSetDevice(root.device));
-        for (uint32_t g = 1; g < groups; ++g) {
-            rr_multi::Dev& src = m->devs[b * groups + g];
-            HIP_TRY(hipStreamWaitEvent(root.stream, src.done, 0));
-            for (int which = 0; which < 2; ++which) {
-                float* from = which == 0 ? src.resolved : src.linear;
-                float* to = which == 0 ? root.resolved : root.linear;
-                if (which == 1 && !out_linear) continue;
-                HIP_TRY(hipMemcpyPeerAsync(root.stage, root.device, from, src.device, n * sizeof(float), root.stream));
-                hipLaunchKernelGGL(k_add_images, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, root.stream, to, root.stage, n);
+        if (use_rccl) {
+            // one ncclReduce(sum, f32) over the band's devices, each on the stream its render was enqueued on, root = the band's
+            // first device, in place there: `resolved` and `linear` travel together (they are one allocation)
+            const std::vector<ncclComm_t>& comms = m->comms[groups];
+            Rccl& R = rccl();
+            ncclResult_t nr = R.GroupStart();
+            for (uint32_t g = 0; g < groups && nr == ncclSuccess; ++g) {
+                rr_multi::Dev& d = m->devs[b * groups + g];
+                HIP_TRY(hipSetDevice(d.device));
+                nr = R.Reduce(d.resolved, d.resolved, n * 2u, ncclFloat, ncclSum, 0, comms[b * groups + g], d.stream);
+            }
+            const ncclResult_t ne = R.GroupEnd();
+            if (nr == ncclSuccess) nr = ne;
+            if (nr != ncclSuccess) return fail(RR_E_HIP, std::string("rr_multi_render: ncclReduce failed: ") + R.GetErrorString(nr));
+            HIP_TRY(hipSetDevice(root.device));
+        } else {
+            HIP_TRY(hipSetDevice(root.device));
+            for (uint32_t g = 1; g < groups; ++g) {
+                rr_multi::Dev& src = m->devs[b * groups + g];
+                HIP_TRY(hipStreamWaitEvent(root.stream, src.done, 0));
+                const uint64_t count = out_linear ? n * 2u : n;  // (both images are adjacent on either side)
+                HIP_TRY(hipMemcpyPeerAsync(root.stage, root.device, src.resolved, src.device, count * sizeof(float), root.stream));
+                hipLaunchKernelGGL(k_add_images, dim3(static_cast<uint32_t>((count + 255u) / 256u)), dim3(256), 0, root.stream, root.resolved, root.stage, count);
                 HIP_TRY(hipGetLastError());
             }
         }

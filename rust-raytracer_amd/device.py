@@ -78,7 +78,7 @@ class Context:
         _check(self._l.rr_scene_info_get(self._h, C.byref(i)))
         return dict(stack_words=i.stack_words, max_inst_depth=i.max_inst_depth, device_bytes=i.device_bytes,
                     n_prims=i.n_prims, wavefront=bool(i.wavefront), bvh_nodes_by_class=list(i.bvh_nodes_by_class),
-                    subtree_ops=list(i.subtree_ops))
+                    subtree_ops=list(i.subtree_ops), workspace_bytes=i.workspace_bytes)
 
     def primary_hits(self, rays, t_min=0.001, t_max=3.40282347e38, seed=0):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
@@ -132,13 +132,26 @@ class Context:
 class MultiContext:
     """Several GPUs driven from this one process (rr_multi_*): the in-process counterpart of rust_raytracer_amd.multi."""
 
-    def __init__(self, devices):
+    REDUCE = {"auto": abi.REDUCE_AUTO, "peer": abi.REDUCE_PEER, "rccl": abi.REDUCE_RCCL}
+
+    def __init__(self, devices, reduce="auto"):
         self._l = lib()
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
         _check(self._l.rr_multi_create(len(devices), arr, C.byref(h)))
         self._h = h
         self.devices = list(devices)
+        if reduce != "auto":
+            self.set_reduce(reduce)
+
+    def set_reduce(self, mode):
+        """How a band's slice groups are summed: "auto" (RCCL when it applies, else peer copies), "peer", "rccl" (or fail)."""
+        _check(self._l.rr_multi_set_reduce(self._h, self.REDUCE[mode]))
+
+    def info(self):
+        used = C.c_uint32(0)
+        _check(self._l.rr_multi_reduce_used(self._h, C.byref(used)))
+        return dict(reduce={abi.REDUCE_PEER: "peer", abi.REDUCE_RCCL: "rccl"}[used.value])
 
     def close(self):
         if getattr(self, "_h", None):

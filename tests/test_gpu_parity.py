@@ -6,6 +6,7 @@ least 98 % of the channels (paths share their random numbers with the oracle, so
 paths that a last-bit difference in sin/cos/log10 sent somewhere else) and image means within 1 %.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -754,6 +755,62 @@ def test_in_process_multi_device_entry(gpu_ctx, name):
         device.MultiContext([0, 99])
 
 
+def test_in_process_sum_over_rccl(gpu_ctx):
+    """The RCCL route of rr_multi_render (ncclReduce per band, librccl.so opened at run time).  This box has one GPU and a
+    communicator cannot hold a device twice, so what runs here is the binding itself — dlopen, ncclCommInitAll, a grouped
+    ncclReduce of `resolved` and `linear` in one call on the render's stream, communicator reuse and destruction — on
+    bands of ONE device (forced mode sends those through the reduce too: a copy in place), against the single-context image;
+    and the decisions: a device listed twice is refused in forced mode and takes the peer-copy sum in auto mode.  The sum of
+    two or more GPUs over xGMI is unmeasured on hardware."""
+    from rust_raytracer_amd import multi
+    b, flat, _ = config_scene("cornell")
+    gpu_ctx.upload(flat)
+    job = multi.job_params(90, 61, 24, 8, 30, 5)
+    whole = gpu_ctx.render(job)
+    mc = device.MultiContext([0], reduce="rccl")
+    mc.upload(flat)
+    for split in (abi.SPLIT_SLICES, abi.SPLIT_ROWS):
+        for _ in range(2):  # the second call reuses the communicator
+            r = mc.render(job, split)
+            assert mc.info()["reduce"] == "rccl"
+            assert np.array_equal(r["resolved"], whole["resolved"]) and np.array_equal(r["linear"], whole["linear"], equal_nan=True)
+            assert np.array_equal(r["rgb8"], whole["rgb8"]) and counts(r) == counts(whole)
+    small = multi.job_params(33, 20, 8, 4, 10, 6)
+    assert np.array_equal(mc.render(small, abi.SPLIT_SLICES)["rgb8"], gpu_ctx.render(small)["rgb8"])
+    mc.set_reduce("peer")
+    assert np.array_equal(mc.render(job, abi.SPLIT_SLICES)["rgb8"], whole["rgb8"]) and mc.info()["reduce"] == "peer"
+    mc.close()
+    twice = device.MultiContext([0, 0], reduce="rccl")
+    twice.upload(flat)
+    with pytest.raises(device.DeviceError, match="distinct devices"):
+        twice.render(job, abi.SPLIT_SLICES)
+    r = twice.render(job, abi.SPLIT_ROWS)  # two bands of one device each: two communicators of one rank
+    assert np.array_equal(r["rgb8"], whole["rgb8"]) and twice.info()["reduce"] == "rccl"
+    twice.set_reduce("auto")
+    r = twice.render(job, abi.SPLIT_SLICES)
+    assert twice.info()["reduce"] == "peer" and np.abs(r["rgb8"].astype(int) - whole["rgb8"].astype(int)).max() <= 1
+    twice.close()
+
+
+def test_bench_drives_the_number_of_gpus_it_is_asked_for():
+    """bench.py on this one-GPU box: --gpus 2 must fail (one GPU visible) without printing a result line; the in-process
+    route over the device listed twice reports two ranks on one GPU."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(abi.REPO_DIR, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "cornell", "--spp", "16"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing to measure fewer GPUs than asked" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, bench, "--inprocess", "--devices", "0,0", "--workload", "cornell", "--spp", "64", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_ranks_seen"] == 2 and out["n_gpus"] == 1 and out["scaling"] == "strong"
+    assert out["value"] > 100.0 and "slices" in out["config"]["parallelism"]
+
+
 def test_full_size_cornell_configuration(gpu_ctx):
     """The headline benchmark configuration at full size (Cornell box, 600x600, 1000 spp, depth 200): every sample is traced,
     nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""
@@ -800,6 +857,12 @@ def test_full_size_bvh_configurations(gpu_ctx, name, depth, spp):
     other = gpu_ctx.render(device.make_params(800, 800, 64, n_slices=8, max_depth=depth, seed=99), slice_sums=False)
     m_whole, m_other = whole["linear"].mean() / spp, other["linear"].mean() / 64.0
     assert abs(m_whole - m_other) < 0.02 * m_other, (m_whole, m_other)
+    # the CPU side of the same check: the oracle's render of the same camera at 200x200 (a regular subsample of the 800x800
+    # pixels' directions up to the jitter) and 64 spp with its own random numbers has the same image energy
+    ref = O.render(flat, O.make_params(200, 200, 64, n_slices=8, max_depth=depth, seed=77), n_threads=16)
+    m_ref = float(np.nanmean(ref["linear"])) / 64.0
+    assert np.isfinite(ref["linear"]).all()
+    assert abs(m_whole - m_ref) < 0.01 * m_ref, (m_whole, m_ref)
 
 
 @pytest.mark.parametrize("name,side,spp,depth", [("cornell", 96, 512, 50), ("suzanne", 64, 256, 50), ("final", 48, 256, 30)])

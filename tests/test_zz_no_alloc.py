@@ -51,6 +51,44 @@ def test_noalloc_entry_equals_render_device_on_calls_in_a_row(gpu_ctx, name):
     _assert_same(a2, b2)
 
 
+def test_noalloc_entry_allocates_nothing():
+    """On a context of its own whose only renders go through rr_render_device_noalloc: the context's workspace stays
+    unallocated (rr_scene_info.workspace_bytes == 0: nothing was hipMalloc'ed behind the call), and the free device memory the
+    runtime reports is the same before and after warm calls (the first call of a kernel may make the runtime allocate its
+    private-segment scratch, so the comparison starts after one call of every kernel build involved)."""
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for name in ("cornell", "final"):
+        b, flat, _ = host.build_config_scene(name)
+        ctx = device.Context(0)
+        try:
+            ctx.upload(flat)
+            p = device.make_params(320, 200, 24, n_slices=4, max_depth=20, seed=9)
+            sums = torch.empty((4, 200, 320, 3), dtype=torch.float32, device=dev)
+            resolved = torch.empty((200, 320, 3), dtype=torch.float32, device=dev)
+            linear = torch.empty((200, 320, 3), dtype=torch.float32, device=dev)
+            counters = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=dev)
+            args = (p, sums.data_ptr(), resolved.data_ptr(), linear.data_ptr(), counters.data_ptr(), stream)
+            ctx.render_device_noalloc(*args)  # warm: code objects loaded, runtime scratch in place
+            torch.cuda.synchronize()
+            first = resolved.cpu().numpy()
+            free_before, _ = torch.cuda.mem_get_info()
+            for _ in range(3):
+                ctx.render_device_noalloc(*args)
+            torch.cuda.synchronize()
+            free_after, _ = torch.cuda.mem_get_info()
+            assert free_after == free_before, (name, free_before, free_after)
+            assert ctx.info()["workspace_bytes"] == 0, name
+            assert np.array_equal(resolved.cpu().numpy(), first)
+            # the allocating entry on the same context does allocate, and the getter sees it
+            ctx.render_device(*args)
+            torch.cuda.synchronize()
+            assert ctx.info()["workspace_bytes"] > 0
+            assert np.array_equal(resolved.cpu().numpy(), first)
+        finally:
+            ctx.close()
+
+
 def test_noalloc_entry_rejects_what_it_cannot_hold(gpu_ctx):
     b, flat, _ = host.build_config_scene("cornell")
     gpu_ctx.upload(flat)
