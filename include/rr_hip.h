@@ -268,6 +268,11 @@ typedef struct rr_render_params {
  * subtrees culled), with the counters of rr_counters switched on.  Excludes RR_FLAG_COUNTERS, whose build of
  * the kernels makes (and counts) every visit of the reference instead.  Same image as either.           */
 #define RR_FLAG_COUNT_PRODUCTION 32u
+/* In scenes whose BVH nodes are all of the culling classes (rr_scene_info.wide_nodes) the traversal kernel of the wavefront
+ * pipeline walks the BVHs with a node move that tests the boxes of both children of a node from one 64-byte record and
+ * fetches only the children the ray can reach; this flag keeps it to the move that tests one box per visited node, which
+ * every other kernel uses (for measurements and tests: same image).                                                     */
+#define RR_FLAG_NARROW_NODES 64u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */
@@ -306,6 +311,8 @@ typedef struct rr_scene_info {
                                        [3] the same against [0,inf) (triangles below)                              */
     uint32_t subtree_ops[2]; /* BVH subtrees the scene program hands to the per-lane machine: [0] to the moves for BVH nodes over
                                 spheres, rects, triangles and cuboids whose root box holds every box below, [1] to the general machine */
+    uint32_t wide_nodes;     /* 1: the wavefront pipeline walks the BVHs with the two-boxes-per-node move (every BVH node is of class
+                                [2] or [3] and has only BVH nodes, spheres, rects, triangles and cuboids below; reference semantics) */
     uint64_t workspace_bytes; /* device memory the context's render calls have allocated so far (grow-only workspace and work
                                 counter of rr_render_device / rr_render); stays 0 on a context that only ever rendered through
                                 rr_render_device_noalloc                                                                    */

@@ -63,6 +63,7 @@ if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"))
 bench = last_json_line(os.path.join(src, "bench_under_trace.json"))
 out["bench_under_trace"] = bench
+out["source_sha256"] = bench.get("source_sha256")  # the device sources the profiled kernels were built from (bench.py compares)
 
 # per-kernel time of the timed steps (the warm-up step and the instrumented pass excluded)
 trace = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
@@ -114,6 +115,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 out["pmc_timed_step"] = pmc
 if pmc_bench:
     out["bench_under_pmc"] = {k: pmc_bench[k] for k in ("value", "ms_per_step", "mrays_per_s", "config")}
+    out["pmc_spp"] = pmc_bench["config"]["spp"]
+    if pmc_bench.get("source_sha256") != out["source_sha256"]:
+        raise SystemExit("the trace pass and the PMC passes ran different device sources")
     rays = pmc_bench["roofline"]["rays_per_launch"]
     samples = pmc_bench["value"] * 1e6 * pmc_bench["ms_per_step"] * 1e-3
     tot = collections.Counter()
@@ -152,10 +156,41 @@ if pmc_bench:
         tpath = os.path.join(dst, f"{tag}_pmc_traffic.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
         t[workload] = {"hbm_bytes_per_sample": derived["hbm_bytes_per_sample"], "hbm_fetch_bytes": round(fetch),
-                       "hbm_write_bytes": round(write), "samples": round(samples),
+                       "hbm_write_bytes": round(write), "samples": round(samples), "source_sha256": out["source_sha256"],
+                       "pmc_spp": out.get("pmc_spp"),
                        "note": "FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte reads at 64 bytes) + WRITE_SIZE x 1024, "
                                "summed over the timed step's path-tracing kernels; Infinity-Cache hits are included"}
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
+        if k_ms:
+            derived["hbm_gbs"] = round((fetch + write) / (k_ms * 1e-3) / 1e9, 1)
+    if tot.get("TCC_HIT_sum") is not None and tot.get("TCC_MISS_sum") is not None and (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]) > 0:
+        derived["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4)
+    if tot.get("TCC_REQ_sum") and k_ms:
+        derived["l2_requests_per_ray"] = round(tot["TCC_REQ_sum"] / rays, 2)
+    if tot.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        derived["l1_accesses_per_ray"] = round(tot["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays, 2)
+        if tot.get("TCP_TCC_READ_REQ_sum") is not None:
+            derived["l1_read_miss_per_ray"] = round(tot["TCP_TCC_READ_REQ_sum"] / rays, 2)
+    # per kernel: instructions, lanes and wait split, so that a pipeline of several kernels can be read kernel by kernel
+    per_kernel = {}
+    for k, c in pmc.items():
+        e = {}
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            e["active_lanes_per_valu_inst"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"], 2)
+        if c.get("SQ_WAVE_CYCLES"):
+            e["wave_cycles_split"] = {n: round(c[n] / c["SQ_WAVE_CYCLES"], 4) for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA") if n in c}
+        for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES"):
+            if n in c:
+                e[n] = c[n]
+        if "FETCH_SIZE" in c:
+            e["hbm_fetch_bytes"] = round(c["FETCH_SIZE"] * 2048.0)
+        if "WRITE_SIZE" in c:
+            e["hbm_write_bytes"] = round(c["WRITE_SIZE"] * 1024.0)
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        if e:
+            per_kernel[k] = e
+    derived["per_kernel"] = per_kernel
     # percentages are per dispatch: report their mean over the dispatches of each kernel
     for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         files = newest(os.path.join(d, "*", "*_counter_collection.csv")) if os.path.isdir(d) else []

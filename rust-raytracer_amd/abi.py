@@ -24,6 +24,7 @@ FLAG_WAVEFRONT = 4
 FLAG_NO_FINISH_KERNEL = 8
 FLAG_PATHS = 16
 FLAG_COUNT_PRODUCTION = 32
+FLAG_NARROW_NODES = 64
 N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304
@@ -155,7 +156,7 @@ class Hit(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("stack_words", u32), ("max_inst_depth", u32), ("device_bytes", u64), ("n_prims", u32),
                 ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4), ("subtree_ops", u32 * 2),
-                ("workspace_bytes", u64)]
+                ("wide_nodes", u32), ("workspace_bytes", u64)]
 
 
 class PresetOptions(C.Structure):

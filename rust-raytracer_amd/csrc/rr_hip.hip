@@ -334,6 +334,7 @@ struct rr_context {
     bool lean_scene = false;  // no OP_MED_BEGIN / MID / END in the program, every cuboid the constructor's, instances at most two deep
     bool has_subtrees = false;
     bool has_general_subtrees = false;  // OP_SUBTREE ops: subtrees the simple machine moves do not cover
+    bool wide_scene = false;  // the production kernels walk the BVHs with the wide node move (rr_scene_upload says when)
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
     bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
     uint32_t root = NONE;
@@ -894,8 +895,10 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     using TraverseKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, uint32_t, unsigned long long*);
     using FinishKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, unsigned long long*);
     const bool ref_sem = ctx->sc.intended == 0u;  // (the production kernels have a build that knows the semantics switch is off)
-    const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? k_wf_traverse<COUNT_PRODUCTION>
+    const bool wide = ctx->wide_scene && !(flags & RR_FLAG_NARROW_NODES);  // (a wide scene has the reference's semantics and no general subtrees)
+    const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? (wide ? k_wf_traverse<COUNT_PRODUCTION, false, true> : k_wf_traverse<COUNT_PRODUCTION>)
                                       : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE>
+                                      : wide ? k_wf_traverse<COUNT_OFF, true, true>
                                       : ref_sem ? k_wf_traverse<COUNT_OFF, true> : k_wf_traverse<COUNT_OFF>;
     const FinishKernel k_finish = count == COUNT_PRODUCTION ? k_wf_finish<COUNT_PRODUCTION>
                                   : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE>
@@ -931,6 +934,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
         WfCtl* ctl = ws[w].ctl;
         a.s0 = s0;
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        a.n_sub = a.pass_slices * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
         // the workspace is free once the batch that used it last has been accumulated
         if (n_batches >= (two ? 2u : 1u)) HIP_TRY(hipStreamWaitEvent(stream, ctx->wf_ev_aux[w], 0));
         uint32_t finish_bound = 0;  // upper bound of the number of paths handed to k_wf_finish (0: none are)
@@ -1032,6 +1036,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
         a.s0 = s0;
         a.n_paths = a.n_slots * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
+        a.n_sub = a.pass_slices * static_cast<uint32_t>(std::min<uint64_t>(batch, a.spt - s0));
         if (a.n_paths != 0) {
             HIP_TRY(hipMemsetAsync(next_path, 0, sizeof(unsigned long long), stream));
             const uint32_t g = std::min<uint32_t>(static_cast<uint32_t>(grid), (a.n_paths + 255u) / 256u);
@@ -1239,6 +1244,37 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         bvh_class[i] = static_cast<uint8_t>(cls);
         if (wk.seen[RR_TAG_BVH][i]) class_count[cls]++;
     }
+    // The wide node move (trav_node_wide, the wavefront pipeline's traversal kernel) tests the boxes of a node's two children
+    // from one 64-byte record of the node.  It is for scenes under the reference's semantics in which every BVH node of the
+    // tree is of a culling class and has nothing but BVH nodes, spheres, rects, triangles and cuboids below it; such scenes
+    // get the records when they are ones the pipeline renders, the others keep the one-box-per-visit moves.
+    bool wide_scene = s->semantics != RR_SEMANTICS_INTENDED && s->n_bvh_nodes != 0;
+    for (uint32_t i = 0; i < s->n_bvh_nodes && wide_scene; ++i)
+        if (wk.seen[RR_TAG_BVH][i])
+            wide_scene = bvh_class[i] >= BVH_CLASS_CULL_RANGE && wk.bvh_below[i].simple;
+    std::vector<float4> wide;
+    if (wide_scene) {
+        wide.resize(static_cast<size_t>(s->n_bvh_nodes) * 4);
+        for (uint32_t i = 0; i < s->n_bvh_nodes; ++i) {
+            const rr_bvh_node& n = s->bvh_nodes[i];
+            if (!wk.seen[RR_TAG_BVH][i]) {  // not part of the tree: never visited, its refs were never checked
+                for (int k = 0; k < 4; ++k) wide[4 * static_cast<size_t>(i) + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            const uint32_t child[2] = {n.left, n.right};
+            for (int c = 0; c < 2; ++c) {
+                float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+                uint32_t cls = 0;  // a primitive: no box to test
+                if (RR_REF_TAG(child[c]) == RR_TAG_BVH) {
+                    const rr_bvh_node& cn = s->bvh_nodes[RR_REF_INDEX(child[c])];
+                    for (int a = 0; a < 3; ++a) lo[a] = cn.bmin[a], hi[a] = cn.bmax[a];
+                    cls = bvh_class[RR_REF_INDEX(child[c])];
+                }
+                wide[4 * static_cast<size_t>(i) + 2 * c] = make_float4(lo[0], lo[1], lo[2], u2f(to_dref(child[c], c == 0 ? n.axis : 0u)));
+                wide[4 * static_cast<size_t>(i) + 2 * c + 1] = make_float4(hi[0], hi[1], hi[2], u2f(cls));
+            }
+        }
+    }
     std::vector<float4> sphere(s->n_spheres + PAD);
     std::vector<uint2> sphere_meta(s->n_spheres);
     ctx->id_sphere.resize(s->n_spheres);
@@ -1383,7 +1419,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevConst> kc(1);
     DevConst& k = kc[0];
     const uint4* prog_dev = nullptr;
-    if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &k.sphere_meta)) ||
+    if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, wide, &d.wide)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &k.sphere_meta)) ||
         (rc = upload(mem, msphere, &d.msphere)) || (rc = upload(mem, rect, &d.rect)) || (rc = upload(mem, tri, &d.tri)) ||
         (rc = upload(mem, tri_meta, &k.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
         (rc = upload(mem, inst, &d.inst)) || (rc = upload(mem, chain_rec, &d.chain_rec)) || (rc = upload(mem, list, &d.list)) ||
@@ -1417,6 +1453,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.device_bytes = mem.bytes;
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
     ctx->has_triangles = s->n_triangles != 0;
+    ctx->wide_scene = wide_scene;
+    ctx->info.wide_nodes = wide_scene ? 1u : 0u;
     ctx->lean_scene = all_canonical && wk.max_inst_depth <= 2;
     ctx->has_subtrees = false;
     ctx->has_general_subtrees = false;
@@ -1580,6 +1618,10 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
         for (uint32_t s0 = 0; s0 < n_sl; s0 += group) {
             const uint32_t here = std::min(group, n_sl - s0);
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
+            w.pass_slices = here;
+            w.strip_pixels = 0;
+            if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
+                w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
             w.slice_first = p->slice_begin + s0;
             w.slice_out = s0;
             int rc;

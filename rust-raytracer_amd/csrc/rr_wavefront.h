@@ -40,7 +40,7 @@ constexpr uint32_t WF_STAGE = 1024;  // queue entries a shading wave collects be
 // A wave fetches new rays once this many of its lanes have none.  Measured on the triangle-mesh and the
 // final scene: 8: -10 %, 16: 0, 32: +12 %, 40-48: +13 %, 64 (never refill a running wave): +3 %.  A refill
 // stalls the lanes still traversing for two dependent loads and three divisions, so it has to fill many.
-#define RR_WF_REFILL_IDLE 40
+#define RR_WF_REFILL_IDLE 16
 #endif
 
 struct WfState {     // one entry per path in each array
@@ -50,9 +50,14 @@ struct WfState {     // one entry per path in each array
                      // its sample value once it has ended
     uint4* hit;      // (t, primitive ref, material, owner word) of the closest hit, ref NONE for a miss
 };
+#ifndef RR_WF_STRIP_ROWS
+#define RR_WF_STRIP_ROWS 4u  // image rows per strip of the wavefront pipeline's path numbering (0: sample-major numbering)
+#endif
+constexpr uint32_t WF_XCDS = 8;  // accelerator dies of an MI355X, each with an L2 of its own
 struct WfCtl {
     uint32_t count;   // entries in the queue
     uint32_t cursor;  // next entry no traversal wave has claimed yet
+    uint32_t xcur[WF_XCDS];  // k_wf_traverse: per eighth of the queue, how far into it entries have been claimed
 };
 struct WfArgs {
     uint32_t width, height;  // of the whole image
@@ -68,15 +73,56 @@ struct WfArgs {
     uint32_t sample_offset;
     uint32_t stack_words;  // words of traversal stack per lane: the wave's slots for parked lanes follow the stacks in LDS
     uint32_t paths_chunk;  // k_wf_paths: paths a wave claims at a time (0: RR_PATHS_CHUNK)
+    uint32_t strip_pixels; // wavefront pipeline: paths are numbered strip by strip (see wf_path_key); 0: sample-major over the whole band
+    uint32_t pass_slices;  // n_slots / n_pixels: slices in this pass
+    uint32_t n_sub;        // (samples in this batch) * pass_slices: the paths of one pixel in this batch
     uint64_t seed;
 };
 
+// How the paths of a batch are numbered.  The persistent kernel k_wf_paths numbers them sample-major: path p is sample
+// s0 + p / n_slots of slot p % n_slots, slot = slice * n_pixels + pixel.  The wavefront pipeline (scenes larger than the
+// L2s) numbers them strip by strip (a.strip_pixels != 0): a strip is a few image rows, and all of a strip's paths — every
+// slice and batch sample of its pixels — come before the next strip's, pixel fastest.  Rays that are neighbours in the queue
+// are then neighbours in the image whatever their sample number, and a contiguous range of the queue is a band of the image:
+// that is what lets each die keep its part of the scene in its own L2 (k_wf_traverse).  The numbering changes no result:
+// every random stream is keyed by (pixel, sample), and k_wf_accumulate adds a pixel's samples in sample order either way.
+// STRIPS = false: a build that knows the numbering is sample-major.
+struct WfPathPos {
+    uint32_t pix;  // pixel within the band of rows
+    uint32_t sub;  // s_local * pass_slices + slice_local
+};
+template <bool STRIPS = true>
+__device__ __forceinline__ WfPathPos wf_path_pos(const WfArgs& a, uint32_t p) {
+    if (!STRIPS || a.strip_pixels == 0u) {
+        const uint32_t slot = p % a.n_slots, s = p / a.n_slots;
+        return WfPathPos{slot % a.n_pixels, s * a.pass_slices + slot / a.n_pixels};
+    }
+    const uint32_t per_strip = a.strip_pixels * a.n_sub;
+    const uint32_t strip = p / per_strip, rem = p - strip * per_strip;
+    const uint32_t first = strip * a.strip_pixels;
+    const uint32_t len = min(a.strip_pixels, a.n_pixels - first);  // (the last strip may be shorter)
+    const uint32_t sub = rem / len;
+    return WfPathPos{first + (rem - sub * len), sub};
+}
+__device__ __forceinline__ uint32_t wf_path_index(const WfArgs& a, uint32_t pix, uint32_t sub) {
+    if (a.strip_pixels == 0u) return (sub / a.pass_slices) * a.n_slots + (sub % a.pass_slices) * a.n_pixels + pix;
+    const uint32_t strip = pix / a.strip_pixels, first = strip * a.strip_pixels;
+    const uint32_t len = min(a.strip_pixels, a.n_pixels - first);
+    return first * a.n_sub + sub * len + (pix - first);
+}
 // (pixel, per-pixel sample number) of a path: the key of its random streams.  The pixel is its position in the whole
 // image (row * width + column), whichever band of rows is being rendered.
+template <bool STRIPS = true>
 __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_t& pixel, uint32_t& sample) {
-    const uint32_t slot = p % a.n_slots, s = a.s0 + p / a.n_slots;
-    pixel = a.pixel0 + slot % a.n_pixels;
-    sample = a.sample_offset + (a.slice_first + slot / a.n_pixels) * a.spt + s;
+    if (!STRIPS) {
+        const uint32_t slot = p % a.n_slots, s = a.s0 + p / a.n_slots;
+        pixel = a.pixel0 + slot % a.n_pixels;
+        sample = a.sample_offset + (a.slice_first + slot / a.n_pixels) * a.spt + s;
+        return;
+    }
+    const WfPathPos q = wf_path_pos<true>(a, p);
+    pixel = a.pixel0 + q.pix;
+    sample = a.sample_offset + (a.slice_first + q.sub % a.pass_slices) * a.spt + a.s0 + q.sub / a.pass_slices;
 }
 
 // render.rs:95-98: every path of the batch starts at its camera ray with throughput one and full depth.
@@ -103,6 +149,7 @@ __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState 
         ctl[0].cursor = 0;
         ctl[1].count = ctl[1].cursor = 0;
         ctl[2].count = ctl[2].cursor = 0;
+        for (uint32_t x = 0; x < WF_XCDS; ++x) ctl[0].xcur[x] = ctl[1].xcur[x] = ctl[2].xcur[x] = 0;
         if (counters) atomicAdd(&counters[0], static_cast<unsigned long long>(a.n_paths));  // samples started: one per path
     }
 }
@@ -113,8 +160,9 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
     if (slot >= a.n_slots) return;
     float* dst = slice_sums + (static_cast<uint64_t>(a.slice_out) * a.n_pixels + slot) * 3u;
     f3 acc = a.s0 == 0 ? mk3(0.f, 0.f, 0.f) : mk3(dst[0], dst[1], dst[2]);
-    for (uint32_t p = slot; p < a.n_paths; p += a.n_slots) {
-        const float4 c = st.thr[p];
+    const uint32_t pix = slot % a.n_pixels, slice = slot / a.n_pixels;
+    for (uint32_t sub = slice; sub < a.n_sub; sub += a.pass_slices) {  // this slot's samples of the batch, in sample order
+        const float4 c = st.thr[wf_path_index(a, pix, sub)];
         acc = acc + mk3(c.x, c.y, c.z);
     }
     dst[0] = acc.x, dst[1] = acc.y, dst[2] = acc.z;
@@ -194,7 +242,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
             if (!path_active && rank < take) {
                 p = chunk_pos + rank;
-                wf_path_key(a, p, pixel, sample);
+                wf_path_key<false>(a, p, pixel, sample);
                 Rng g;
                 g.start(a.seed, pixel, sample, CAMERA_BOUNCE);
                 camera_ray(sc, a.width, a.height, pixel % a.width, a.height - 1u - pixel / a.width, g, ro, rd, time);
@@ -290,7 +338,9 @@ struct WfDraw {
     }
 };
 
-template <int COUNT, bool REF_SEM = false>  // REF_SEM: as for k_wf_paths
+// WIDE: every BVH node is walked with the wide node move (trav_node_wide): the host asks for it only when all of them are of a
+// culling class, none has anything but BVH nodes, spheres, rects, triangles and cuboids below, and the semantics are the reference's.
+template <int COUNT, bool REF_SEM = false, bool WIDE = false>  // REF_SEM: as for k_wf_paths
 __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     k_wf_traverse(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
                   unsigned long long* counters) {
@@ -312,26 +362,44 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     // and at a few nanoseconds each a claim per refill would cost as much as the traversal itself).
     // Chunks are sized so that every wave makes several claims, which evens out the finish.
     const uint32_t n_waves = gridDim.x * (blockDim.x / 64u);
-    const uint32_t chunk = min(max(total / (n_waves * 8u), 64u), 4096u);
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: the unclaimed rest of this wave's chunk
+    // The queue is cut into one contiguous part per die (XCD): a wave claims from the part of the die it runs on and, once that
+    // is used up, from the next die's.  Neighbours in the queue are neighbours in the image (wf_path_key), so a die's rays walk
+    // the same region of the scene and its L2 (4 MB, not shared between dies) serves more of their fetches than when every die
+    // sees every region.  A claim is a fraction of what is left of the part (at least 64 entries, at most 4096), so the claims
+    // shrink towards the end and the waves finish together whatever the rays of the last entries cost.
+    const uint32_t xcd = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & (WF_XCDS - 1u);  // HW_REG_XCC_ID, bits 3..0
+    uint32_t part = xcd, parts_tried = 0;
     // Every lane leaves through the same wave-wide vote, after the queue is drained and the last
     // ray of the wave has finished.
     for (;;) {
         const uint64_t idle = RR_BALLOT(!active);
         if (!exhausted && __popcll(idle) >= RR_WF_REFILL_IDLE) {
-            if (chunk_pos == chunk_end) {
-                uint32_t base = 0;
-                if ((threadIdx.x & 63u) == 0) base = atomicAdd(&ctl->cursor, chunk);
+            while (chunk_pos == chunk_end && parts_tried < WF_XCDS) {
+                const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(total) * part / WF_XCDS),
+                               hi = static_cast<uint32_t>(static_cast<uint64_t>(total) * (part + 1u) / WF_XCDS);
+                uint32_t base = 0, chunk = 0;
+                if ((threadIdx.x & 63u) == 0) {
+                    const uint32_t seen = min(__hip_atomic_load(&ctl->xcur[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi - lo);
+                    chunk = min(max((hi - lo - seen) / (n_waves / WF_XCDS * 2u + 1u), 64u), 4096u);
+                    base = atomicAdd(&ctl->xcur[part], chunk);
+                }
                 base = __builtin_amdgcn_readfirstlane(base);
-                chunk_pos = min(base, total);
-                chunk_end = min(base + chunk, total);
+                chunk = __builtin_amdgcn_readfirstlane(chunk);
+                if (base >= hi - lo) {  // this part is used up (its counter only grows): on to the next die's
+                    part = (part + 1u) & (WF_XCDS - 1u);
+                    parts_tried += 1;
+                    continue;
+                }
+                chunk_pos = lo + base;
+                chunk_end = min(chunk_pos + chunk, hi);
             }
+            exhausted = chunk_pos == chunk_end;  // every part is used up: nothing is left for anyone
             const uint32_t want = static_cast<uint32_t>(__popcll(idle));
             const uint32_t take = min(want, chunk_end - chunk_pos);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
             const uint32_t entry = chunk_pos + rank;
             chunk_pos += take;
-            exhausted = chunk_pos == chunk_end && chunk_end == total;  // the cursor only grows: nothing is left for anyone
             if (!active && rank < take) {
                 p = queue[entry];
                 const float4 ro = st.ray_o[p], rd = st.ray_d[p];
@@ -352,7 +420,10 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
         const WfWorld world{st, p};
         WfDraw draw{st, a, p, draws};
         if (COUNT) cnt.lane_steps += active ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
-        if (active) trav_node<COUNT>(sc, m, stk, stride, cnt);
+        if (active) {
+            if (WIDE) trav_node_wide<COUNT>(sc, m, stk, stride, cnt);
+            else trav_node<COUNT>(sc, m, stk, stride, cnt);
+        }
         const bool at_leaf = active && trav_at_leaf(m);
         const uint32_t n_leaf = static_cast<uint32_t>(__popcll(RR_BALLOT(at_leaf)));
         const uint32_t n_node = static_cast<uint32_t>(__popcll(RR_BALLOT(active && trav_at_node(m))));
@@ -360,7 +431,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
             if (at_leaf) trav_leaf<COUNT>(sc, m, world, stk, stride, cnt);
         }
         if (active) {
-            trav_pop<COUNT>(sc, m, world, draw, stk, stride, cnt);
+            trav_pop<COUNT, WfWorld, WfDraw, WIDE>(sc, m, world, draw, stk, stride, cnt);
             draws = draw.n;
             if (m.finished()) {
                 // the hit's material and owner are fetched here, where the latency hides behind other rays' work
@@ -478,6 +549,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the queue two bounces back is free again
         ctl_clear->count = 0;
         ctl_clear->cursor = 0;
+        for (uint32_t x = 0; x < WF_XCDS; ++x) ctl_clear->xcur[x] = 0;
     }
     flush_counts(cnt, counters);
 }

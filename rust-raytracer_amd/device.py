@@ -78,7 +78,8 @@ class Context:
         _check(self._l.rr_scene_info_get(self._h, C.byref(i)))
         return dict(stack_words=i.stack_words, max_inst_depth=i.max_inst_depth, device_bytes=i.device_bytes,
                     n_prims=i.n_prims, wavefront=bool(i.wavefront), bvh_nodes_by_class=list(i.bvh_nodes_by_class),
-                    subtree_ops=list(i.subtree_ops), workspace_bytes=i.workspace_bytes)
+                    subtree_ops=list(i.subtree_ops), wide_nodes=bool(i.wide_nodes),
+                    workspace_bytes=i.workspace_bytes)
 
     def primary_hits(self, rays, t_min=0.001, t_max=3.40282347e38, seed=0):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)

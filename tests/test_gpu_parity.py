@@ -272,6 +272,82 @@ def test_renders_of_random_scenes_agree_between_all_kernel_forms(gpu_ctx, seed):
     assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.995
 
 
+def _random_bvh_scene(seed):
+    """Nothing but what the wide node move is for: BVHs over spheres (tiny and huge), rects, flat and ordinary
+    cuboids and triangles, BVHs inside BVHs, BVHs under instances, next to top-level primitives and a fog."""
+    rng = np.random.default_rng(1000 + seed)
+    b = host.SceneBuilder(seed)
+    mats = [b.lambertian(b.solid_color((0.7, 0.6, 0.5))), b.lambertian(b.checkered((0.1, 0.2, 0.3), (0.9, 0.8, 0.7))),
+            b.glossy((0.8, 0.8, 0.9), 0.3), b.dielectric(1.5), b.emissive((4, 4, 4))]
+
+    def mat():
+        return mats[0] if rng.random() < 0.6 else mats[int(rng.integers(0, len(mats)))]
+
+    def prim(scale, c0):
+        c = c0 + rng.uniform(-scale, scale, 3)
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return b.sphere(c, float(10.0 ** rng.uniform(-2, np.log10(0.4 * scale))), mat())
+        if k == 1:  # (no negative radius: the reference's box of such a sphere is inside out, and a node over it keeps the reference's class)
+            return b.sphere(c, float(rng.uniform(0.05, 0.2) * scale), mat())
+        if k == 2:
+            e = rng.uniform(0.01, 0.5, 2) * scale
+            f = [b.xyrect, b.xzrect, b.yzrect][int(rng.integers(0, 3))]
+            return f(c[0], c[0] + e[0], c[1], c[1] + e[1], float(c[2]), mat())
+        if k == 3:
+            e = rng.uniform(0.0, 0.4, 3) * scale
+            return b.cuboid(c, c + e, mat())
+        p = c + rng.normal(size=(3, 3)) * scale * float(10.0 ** rng.uniform(-2, -0.3))
+        return b.triangle(p[0], p[1], p[2], mat())  # (no slivers: a node over one loses its culling class, and the scene the wide move)
+
+    def group(n, scale, c0):
+        return b.bvh_node([prim(scale, c0) for _ in range(n)])
+
+    zero = np.zeros(3)
+    inner = [group(int(rng.integers(2, 30)), 6.0, rng.uniform(-25, 25, 3)) for _ in range(int(rng.integers(1, 5)))]
+    b.add(b.bvh_node(inner + [prim(30.0, zero) for _ in range(int(rng.integers(20, 300)))]))  # BVHs inside a BVH
+    b.add(group(1, 10.0, rng.uniform(-20, 20, 3)))  # a span-1 tree
+    b.add(group(int(rng.integers(2, 6)), 10.0, rng.uniform(-20, 20, 3)))
+    b.add(b.instance_translation(b.instance_rotation(group(int(rng.integers(5, 80)), 8.0, zero), int(rng.integers(0, 3)),
+                                                     float(rng.uniform(-170, 170))), rng.uniform(-30, 30, 3)))
+    b.add(b.sphere((0, -1000, 0), 985.0, mats[1]))
+    b.add(b.xzrect(-8, 8, -8, 8, 55.0, mats[4]))
+    b.add(b.constant_medium(b.sphere(rng.uniform(-5, 5, 3), 80.0, mats[0]), 0.003, (0.8, 0.9, 1.0)))
+    b.set_lights(b.xzrect(-8, 8, -8, 8, 55.0, mats[4]))
+    b.set_camera((0, 25, -110), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+    b.set_background((0.4, 0.5, 0.8))
+    return b, b.flatten()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_wide_node_move_on_random_bvh_scenes(gpu_ctx, seed):
+    """The node move that tests both children's boxes at their parent (the wavefront pipeline's, for scenes whose BVH nodes
+    are all of a culling class) against the one-box move, the path kernel, the reference-order kernels, the item-granular
+    kernel and the oracle, on randomly built BVH scenes, whole paths: the same bits from every device kernel."""
+    for attempt in range(8):  # (a random triangle can come out a sliver: the node over it keeps the reference's class, and the scene the one-box move)
+        b, flat = _random_bvh_scene(seed + 1000 * attempt)
+        info = gpu_ctx.upload(flat)
+        if info["wide_nodes"]:
+            break
+    assert info["wide_nodes"] and info["subtree_ops"][0] >= 3 and info["subtree_ops"][1] == 0, info
+    kw = dict(n_slices=8, max_depth=25, seed=5)
+    base = gpu_ctx.render(device.make_params(64, 48, 16, **kw))
+    for flags in (abi.FLAG_NARROW_NODES, abi.FLAG_COUNTERS, abi.FLAG_PERSISTENT, abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NARROW_NODES,
+                  abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_COUNT_PRODUCTION, abi.FLAG_WAVEFRONT | abi.FLAG_COUNT_PRODUCTION):
+        other = gpu_ctx.render(device.make_params(64, 48, 16, flags=flags, **kw))
+        assert np.array_equal(base["slice_sums"], other["slice_sums"], equal_nan=True), flags
+        assert other["counters"]["rays"] == base["counters"]["rays"]
+    want = O.render(flat, O.make_params(64, 48, 16, **kw), n_threads=8)
+    nan_got, nan_want = np.isnan(base["slice_sums"]), np.isnan(want["slice_sums"])
+    assert (nan_got == nan_want).mean() > 0.995
+    both = ~nan_got & ~nan_want
+    assert both.mean() > 0.3
+    assert np.isclose(base["slice_sums"][both], want["slice_sums"][both], rtol=1e-3, atol=1e-5).mean() > 0.99
+    rays = _stress_rays(flat, 20_000, seed=300 + seed)
+    rays[:, :3] *= 0.3
+    compare_hits(gpu_ctx.primary_hits(rays, seed=4), O.primary_hits(flat, rays, seed=4), exact_t=False)
+
+
 @pytest.mark.parametrize("which", ["final", "cornell", "suzanne", "random 41", "random 44"])
 def test_fused_ops_of_the_scene_program_equal_the_ops_they_stand_for(gpu_ctx, monkeypatch, which):
     """OP_MED_SPHERE (a medium bounded by a bare sphere: both probes from one discriminant) and OP_XFORM (a run of reset,
@@ -548,12 +624,35 @@ def test_production_counters_count_the_production_traversal(gpu_ctx, name):
         assert 0 < cp["machine_lane_steps"] <= 64 * cp["machine_wave_steps"]
     else:
         assert counts(prod) == counts(ref) and cp["machine_lane_steps"] == 0
+    # The kernel organisations against each other, all with the node move that tests one box per visit (RR_FLAG_NARROW_NODES:
+    # the item-granular kernel has no other).
+    narrow = gpu_ctx.render(device.make_params(60, 44, 6, flags=abi.FLAG_COUNT_PRODUCTION | abi.FLAG_NARROW_NODES, **kw))
+    assert np.array_equal(plain["slice_sums"], narrow["slice_sums"], equal_nan=True)
     for flags in (abi.FLAG_PATHS, abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT):
-        other = gpu_ctx.render(device.make_params(60, 44, 6, flags=flags | abi.FLAG_COUNT_PRODUCTION, **kw))
+        other = gpu_ctx.render(device.make_params(60, 44, 6, flags=flags | abi.FLAG_COUNT_PRODUCTION | abi.FLAG_NARROW_NODES, **kw))
         assert np.array_equal(plain["slice_sums"], other["slice_sums"], equal_nan=True)
         co = counts(other)
-        for k, v in counts(prod).items():
+        for k, v in counts(narrow).items():
             assert co[k] == v if k in ("rays", "samples", "inst_visits") else abs(co[k] - v) <= 0.03 * v, (flags, k, co[k], v)
+    # The wide node move of the wavefront pipeline's traversal kernel (wherever every BVH node is of a culling class: all
+    # three scenes with BVHs here) tests the boxes of both children at their parent: the same primitives are reached (the same
+    # image, the same primitive tests) in fewer steps of the machine; it tests a few more boxes (both children, where the
+    # one-box move would not have come to the second).
+    info = gpu_ctx.info()
+    assert info["wide_nodes"] == (flat.n_bvh_nodes != 0)
+    wide = gpu_ctx.render(device.make_params(60, 44, 6, flags=abi.FLAG_WAVEFRONT | abi.FLAG_COUNT_PRODUCTION, **kw))
+    one = gpu_ctx.render(device.make_params(60, 44, 6, flags=abi.FLAG_WAVEFRONT | abi.FLAG_COUNT_PRODUCTION | abi.FLAG_NARROW_NODES, **kw))
+    assert np.array_equal(plain["slice_sums"], wide["slice_sums"], equal_nan=True)
+    cw, cn = wide["counters"], one["counters"]
+    if info["wide_nodes"]:
+        # (the camera rays walk the whole tree with the wide move; the paths' later rays go through the scene program and
+        # the one-box move with the subtree's margin in both runs, so the counts of the two runs differ by the camera rays')
+        for k in ("rays", "samples", "inst_visits", "sphere_tests", "rect_tests", "tri_tests"):
+            assert cw[k] == cn[k], (k, cw[k], cn[k])
+        assert cn["box_tests"] <= cw["box_tests"] <= 1.35 * cn["box_tests"]
+        assert cw["machine_lane_steps"] < cn["machine_lane_steps"]
+    else:
+        assert counts(wide) == counts(one)
     with pytest.raises(device.DeviceError, match="exclude"):
         gpu_ctx.render(device.make_params(8, 8, 2, flags=abi.FLAG_COUNTERS | abi.FLAG_COUNT_PRODUCTION))
 
@@ -926,6 +1025,15 @@ def test_config5_at_full_size(gpu_ctx):
     hi = gpu_ctx.render(device.make_params(W, H, 2, slice_begin=1, slice_end=2, **kw))
     assert np.array_equal(np.concatenate([lo["slice_sums"], hi["slice_sums"]]), whole["slice_sums"], equal_nan=True)
     assert lo["counters"]["rays"] + hi["counters"]["rays"] == whole["counters"]["rays"]
+    # the image above came from the wavefront pipeline with the wide node move (both children's boxes tested at their parent):
+    # the one-box move and the path kernel (either move) give the same bits on a quarter-size image of the same camera
+    assert info["wide_nodes"] and info["wavefront"]
+    q = dict(n_slices=2, max_depth=50, seed=2)
+    small = gpu_ctx.render(device.make_params(960, 540, 2, **q))
+    for flags in (abi.FLAG_NARROW_NODES, abi.FLAG_PATHS, abi.FLAG_PATHS | abi.FLAG_NARROW_NODES):
+        other = gpu_ctx.render(device.make_params(960, 540, 2, flags=flags, **q))
+        assert np.array_equal(small["slice_sums"], other["slice_sums"], equal_nan=True), flags
+        assert other["counters"]["rays"] == small["counters"]["rays"]
 
 
 # ------------------------------------------------------------------ edge cases
