@@ -324,7 +324,13 @@ typedef struct rr_context rr_context;
 int rr_device_count(int* count);
 
 /* Create / destroy the per-device context.  Fails with RR_E_NO_DEVICE when
- * `device` is not a visible gfx950 GPU: there is no CPU fallback.           */
+ * `device` is not a visible gfx950 GPU: there is no CPU fallback.
+ * Measurement and test switches: rr_context_create reads four environment variables, once, and the context keeps what it
+ * read (a variable set or changed later does nothing).  None of them changes an image; a production host leaves them unset.
+ *   RR_NO_FUSE              the scene program gets one op per transform and per step of a medium instead of the fused ops
+ *   RR_PAD_OPS=n            n ops that do nothing are appended to the scene program (prices an op's fetch and dispatch)
+ *   RR_DUMP_PROGRAM         rr_scene_upload prints the scene program to stderr
+ *   RR_WF_WORKSPACE_BYTES=n caps the workspace of a batch of samples at n bytes (forces many small batches)              */
 int rr_context_create(int device, rr_context** out);
 int rr_context_destroy(rr_context* ctx);
 

@@ -334,6 +334,11 @@ struct rr_context {
     bool lean_scene = false;  // no OP_MED_BEGIN / MID / END in the program, every cuboid the constructor's, instances at most two deep
     bool has_subtrees = false;
     bool has_general_subtrees = false;  // OP_SUBTREE ops: subtrees the simple machine moves do not cover
+    // Measurement and test switches, read from the environment ONCE, when the context is created (include/rr_hip.h documents them)
+    bool sw_no_fuse = false;       // RR_NO_FUSE: one op of the scene program per transform / medium step
+    int sw_pad_ops = 0;            // RR_PAD_OPS=n: n ops that do nothing appended to the scene program
+    bool sw_dump_program = false;  // RR_DUMP_PROGRAM: the scene program to stderr at upload
+    size_t sw_workspace_cap = 0;   // RR_WF_WORKSPACE_BYTES: cap of the per-batch workspace (0: none), to force many small batches
     bool wide_scene = false;  // the production kernels walk the BVHs with the wide node move (rr_scene_upload says when)
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
     bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
@@ -806,7 +811,13 @@ int set_device(rr_context* ctx) {
 int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid) {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
-    if (per_cu < 1) return fail(RR_E_LIMIT, "the scene's traversal stack does not fit the LDS of one CU");
+    if (per_cu < 1) {
+        const size_t stacks = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+        return fail(RR_E_LIMIT, "a workgroup of this kernel needs " + std::to_string(lds_bytes) + " bytes of LDS (" + std::to_string(stacks) +
+                                    " for the traversal stacks of " + std::to_string(ctx->info.stack_words) + " words per lane" +
+                                    (lds_bytes > stacks ? ", " + std::to_string(lds_bytes - stacks) + " for the slots of parked lanes" : std::string()) +
+                                    "), more than one CU gives a workgroup");
+    }
     per_cu = std::min(per_cu, 8);
     *grid = ctx->n_cus * per_cu;
     return RR_OK;
@@ -849,7 +860,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     // per workspace: at most 16 GiB and a quarter of what is free
     const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
     size_t cap = budget;
-    if (const char* env = std::getenv("RR_WF_WORKSPACE_BYTES")) cap = std::max<size_t>(1, std::strtoull(env, nullptr, 10));  // for tests
+    if (ctx->sw_workspace_cap) cap = ctx->sw_workspace_cap;  // (for tests)
     const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, std::max<uint64_t>(1, cap / (80u * static_cast<uint64_t>(a.n_slots))));
     uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(budget / (80u * static_cast<uint64_t>(a.n_slots)), most));
     const bool two = batch < a.spt;  // more than one batch: a second workspace, so that they overlap
@@ -891,7 +902,10 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
         ws[k].ctl = reinterpret_cast<WfCtl*>(base + off_ctl);
     }
 
-    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
+#ifndef RR_WF_TRAVERSE_EXTRA_LDS
+#define RR_WF_TRAVERSE_EXTRA_LDS 0u  // (measurements: bytes of LDS a traversal workgroup asks for beyond its stacks, to lower its occupancy)
+#endif
+    const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + RR_WF_TRAVERSE_EXTRA_LDS;
     using TraverseKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, uint32_t, unsigned long long*);
     using FinishKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, unsigned long long*);
     const bool ref_sem = ctx->sc.intended == 0u;  // (the production kernels have a build that knows the semantics switch is off)
@@ -1020,7 +1034,11 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
         else if (ctx->has_general_subtrees)
             kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, true, true>;
         else
+#ifdef RR_TRI_W4
+            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true, RR_RENDER_WAVES_PER_SIMD, false>;
+#else
             kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true, W5, false>;
+#endif
         // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
         // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
     } else if (ctx->prog_vector_ops) {
@@ -1062,7 +1080,7 @@ int render_paths(rr_context* ctx, WfArgs a, int count, float* sums, unsigned lon
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::max<size_t>(std::min<size_t>(static_cast<size_t>(16) << 30, (free_b + ctx->wf_bytes) / 4), static_cast<size_t>(1) << 20);
     size_t cap = budget;
-    if (const char* env = std::getenv("RR_WF_WORKSPACE_BYTES")) cap = std::max<size_t>(1, std::strtoull(env, nullptr, 10));  // for tests
+    if (ctx->sw_workspace_cap) cap = ctx->sw_workspace_cap;  // (for tests)
     const uint64_t most = std::min<uint64_t>((1ull << 31) / a.n_slots, std::max<uint64_t>(1, cap / (16u * static_cast<uint64_t>(a.n_slots))));
     const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(most, std::max(a.spt, 1u)));
     const size_t need = static_cast<size_t>(a.n_slots) * batch * 16u + 256u;
@@ -1109,6 +1127,10 @@ int rr_context_create(int device, rr_context** out) {
         return fail(RR_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIP_TRY(hipSetDevice(device));
     rr_context* ctx = new rr_context();
+    ctx->sw_no_fuse = std::getenv("RR_NO_FUSE") != nullptr;
+    if (const char* pad = std::getenv("RR_PAD_OPS")) ctx->sw_pad_ops = std::max(0, std::min(std::atoi(pad), 1 << 16));
+    ctx->sw_dump_program = std::getenv("RR_DUMP_PROGRAM") != nullptr;
+    if (const char* env = std::getenv("RR_WF_WORKSPACE_BYTES")) ctx->sw_workspace_cap = std::max<size_t>(1, std::strtoull(env, nullptr, 10));
     ctx->device = device;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->max_dynamic_lds = static_cast<int>(prop.sharedMemPerBlock);
@@ -1388,15 +1410,14 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevImage> images(s->n_images);
     for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
-    ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false, std::getenv("RR_NO_FUSE") == nullptr};
+    ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false, !ctx->sw_no_fuse};
     pb.emit(s->root);
     if (pb.fuse) pb.fuse_transforms();
-    if (const char* pad = std::getenv("RR_PAD_OPS"))  // for measurements: ops that do nothing, to price an op's way through the interpreter
-        for (int i = 0; i < std::atoi(pad); ++i) pb.ops.push_back(ProgramBuilder::make(OP_XFORM));
+    for (int i = 0; i < ctx->sw_pad_ops; ++i) pb.ops.push_back(ProgramBuilder::make(OP_XFORM));  // (for measurements: prices an op's way through the interpreter)
     const uint32_t n_ops = static_cast<uint32_t>(pb.ops.size());
     pb.ops.push_back(ProgramBuilder::make(OP_END));
     pb.ops.push_back(ProgramBuilder::make(OP_END));  // the interpreter prefetches one op past the one it runs
-    if (std::getenv("RR_DUMP_PROGRAM")) {  // for whoever tunes the program: its ops, one per line, to stderr
+    if (ctx->sw_dump_program) {  // for whoever tunes the program: its ops, one per line, to stderr
         static const char* const names[] = {"END", "-", "-", "-", "-", "-", "RECT_XY", "RECT_XZ", "RECT_YZ", "SPHERE", "LEAF_REF",
                                             "SUBTREE", "MED_BEGIN", "MED_MID", "MED_END", "CUBOID", "SUBTREE_SIMPLE", "MED_SPHERE", "XFORM"};
         for (size_t i = 0; i < pb.ops.size(); ++i) {
@@ -1419,6 +1440,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevConst> kc(1);
     DevConst& k = kc[0];
     const uint4* prog_dev = nullptr;
+    const size_t geometry_bytes = (bvh.size() + sphere.size() + msphere.size() + rect.size() + tri.size() + cuboid.size()) * sizeof(float4);
     if ((rc = upload(mem, bvh, &d.bvh)) || (rc = upload(mem, wide, &d.wide)) || (rc = upload(mem, sphere, &d.sphere)) || (rc = upload(mem, sphere_meta, &k.sphere_meta)) ||
         (rc = upload(mem, msphere, &d.msphere)) || (rc = upload(mem, rect, &d.rect)) || (rc = upload(mem, tri, &d.tri)) ||
         (rc = upload(mem, tri_meta, &k.tri_meta)) || (rc = upload(mem, cuboid, &d.cuboid)) || (rc = upload(mem, medium, &d.medium)) ||
@@ -1481,7 +1503,15 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // against 3965 Msamples/s at 1000 spp.  The pipeline keeps the larger ones, whose traversal waits for memory: measured on
     // height fields with spheres of 0.5 / 2 / 5.6 / 20 / 48 / 95 MB (1280x720, 16 spp), path kernel against pipeline: 8.1 / 8.1,
     // 19.9 / 16.5, 54.6 / 40.8, 156 / 100, 358 / 210 ms, and 31.2 against 40.9 Msamples/s on the 1.1 M-primitive mesh.)
-    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && mem.bytes > (1u << 20);
+    // (the threshold is about where the BVHs and primitives stop being cache-resident: textures and tables do not count)
+    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && geometry_bytes > (1u << 20);
+    if (ctx->has_subtrees && lds_bytes + 4u * PARK_LDS_WORDS_PER_WAVE * 4u > static_cast<size_t>(ctx->max_dynamic_lds)) {
+        ctx->scene_mem.release();
+        return fail(RR_E_LIMIT, "rr_scene_upload: traversal stacks of " + std::to_string(stack_words) + " words per lane (" + std::to_string(lds_bytes) +
+                                    " bytes per workgroup) plus " + std::to_string(4u * PARK_LDS_WORDS_PER_WAVE * 4u) +
+                                    " bytes for the slots of parked lanes exceed the " + std::to_string(ctx->max_dynamic_lds) +
+                                    " bytes of LDS available to one workgroup");
+    }
     ctx->root = to_dref(s->root);
     ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
     ctx->sc.no_tri = ctx->sc.lean = 0u;

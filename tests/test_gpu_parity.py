@@ -363,10 +363,14 @@ def test_fused_ops_of_the_scene_program_equal_the_ops_they_stand_for(gpu_ctx, mo
     for no_fuse in (False, True):
         if no_fuse:
             monkeypatch.setenv("RR_NO_FUSE", "1")
-        gpu_ctx.upload(flat)
-        hits = gpu_ctx.primary_hits(rays, seed=4)
-        r = gpu_ctx.render(device.make_params(72, 56, 8, flags=abi.FLAG_COUNTERS, **kw))
-        r2 = gpu_ctx.render(device.make_params(72, 56, 8, **kw))
+        ctx = device.Context(0)  # (a context reads the switch when it is created)
+        try:
+            ctx.upload(flat)
+            hits = ctx.primary_hits(rays, seed=4)
+            r = ctx.render(device.make_params(72, 56, 8, flags=abi.FLAG_COUNTERS, **kw))
+            r2 = ctx.render(device.make_params(72, 56, 8, **kw))
+        finally:
+            ctx.close()
         out.append((hits, r, r2))
     monkeypatch.delenv("RR_NO_FUSE")
     (h0, a0, b0), (h1, a1, b1) = out
@@ -709,10 +713,15 @@ def test_wavefront_batches_overlap_and_accumulate_in_order(gpu_ctx, monkeypatch)
     kw = dict(n_slices=2, max_depth=40, seed=31)
     one = gpu_ctx.render(device.make_params(40, 32, 46, flags=abi.FLAG_PERSISTENT, **kw))
     monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(80 * 2 * 40 * 32 * 5))  # five samples per slot and batch: 5 batches of 23
-    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_PATHS):
-        two = gpu_ctx.render(device.make_params(40, 32, 46, flags=flags, **kw))
-        assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
-        assert counts(one) == counts(two)
+    capped = device.Context(0)  # (a context reads the switch when it is created)
+    try:
+        capped.upload(flat)
+        for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_PATHS):
+            two = capped.render(device.make_params(40, 32, 46, flags=flags, **kw))
+            assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True)
+            assert counts(one) == counts(two)
+    finally:
+        capped.close()
 
 
 def test_path_granular_kernel_equals_item_granular_kernel(gpu_ctx, monkeypatch):
@@ -735,7 +744,12 @@ def test_path_granular_kernel_equals_item_granular_kernel(gpu_ctx, monkeypatch):
     assert np.array_equal(one["slice_sums"], two["slice_sums"]) and two["counters"]["samples"] == 0
     one = gpu_ctx.render(device.make_params(53, 41, 60, flags=abi.FLAG_PERSISTENT, **kw))
     monkeypatch.setenv("RR_WF_WORKSPACE_BYTES", str(16 * 3 * 53 * 41 * 3))  # three samples per slot and batch: 7 batches of 20
-    two = gpu_ctx.render(device.make_params(53, 41, 60, **kw))
+    capped = device.Context(0)  # (a context reads the switch when it is created)
+    try:
+        capped.upload(flat)
+        two = capped.render(device.make_params(53, 41, 60, **kw))
+    finally:
+        capped.close()
     assert np.array_equal(one["slice_sums"], two["slice_sums"], equal_nan=True) and counts(one) == counts(two)
 
 
