@@ -208,7 +208,9 @@ typedef struct rr_flat_scene {
     rr_light light;
     rr_camera camera;
     float background[3];
-    uint32_t semantics;        /* RR_SEMANTICS_*; 0 (a zeroed field) = the reference as it is at HEAD */
+    uint32_t semantics;        /* RR_SEMANTICS_* bits; 0 (a zeroed field) = the reference as it is at HEAD */
+    uint32_t n_lights;         /* RR_SEMANTICS_BOOK_ESTIMATOR only: `lights` was a ColliderList of this many geometries (0: `light` above */
+    const rr_light* lights;    /*   is the `lights` argument, as under every other semantics); is_xzrect = 0 for a member that is no XZRect */
 } rr_flat_scene;
 
 /* Which intersection semantics the scene is traversed with.
@@ -222,9 +224,25 @@ typedef struct rr_flat_scene {
  *                             direction component);
  *                             a triangle rejects hits outside [t_min, t_max] (collider.rs:627 ignores both).
  *                           Everything else (materials, pdfs, media, instances) is unchanged.  With these the BVH returns the
- *                           closest hit in range, as a linear list of the same primitives does.                              */
+ *                           closest hit in range, as a linear list of the same primitives does.
+ *   RR_SEMANTICS_BOOK_ESTIMATOR  a second labelled alternative, a bit of its own (never the default either): what the book the
+ *                           reference follows ("Ray Tracing: The Rest of Your Life", the chapter that cleans up the PDF
+ *                           management) does where the reference's text stops short -
+ *                             a material that scatters and is not Lambertian is specular: ray_color follows the ray the
+ *                             material itself scattered (material.rs:121-154: the fuzzed reflection of a Glossy, the reflected
+ *                             or refracted ray of a Dielectric, the random direction of an Isotropic) and weights it by the
+ *                             attenuation alone, instead of replacing it by a sample of the mixture PDF and weighting it by a
+ *                             scattering pdf of zero (render.rs:27-34 with material.rs:170-175);
+ *                             `lights` may be a ColliderList (rr_flat_scene.lights): its pdf value is the mean of its members'
+ *                             and its sample is one member's, chosen uniformly (member floor(random() * n)); members that are
+ *                             no XZRect have pdf 0 and sample (1,0,0), as collider.rs:714-725 has it for a single geometry.
+ *                           Lambertian surfaces, emission (both faces, material.rs:176-181) and everything else are unchanged.
+ *                           RR_SEMANTICS_BOOK = both bits: the images under output/ of the reference (metal, glass and smoke
+ *                           lit, the whole BVH visible) are of this kind.                                                   */
 #define RR_SEMANTICS_REFERENCE 0u
 #define RR_SEMANTICS_INTENDED 1u
+#define RR_SEMANTICS_BOOK_ESTIMATOR 2u
+#define RR_SEMANTICS_BOOK 3u
 
 /* ---------------------------------------------------------- rendering */
 typedef struct rr_render_params {

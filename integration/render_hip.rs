@@ -259,7 +259,7 @@ pub fn render_hip_on(devices: &[i32], scene: SceneColliders, lights: Geometry, c
         n_perlin: arr(&f.perlin).0, perlin: arr(&f.perlin).1,
         n_images: arr(&images).0, images: arr(&images).1,
         n_image_bytes: image_bytes.len() as u64, image_bytes: if image_bytes.is_empty() { null() } else { image_bytes.as_ptr() },
-        root, light, camera, background: v3(background), semantics: RR_SEMANTICS_REFERENCE,
+        root, light, camera, background: v3(background), semantics: RR_SEMANTICS_REFERENCE, n_lights: 0, lights: null(),
     };
 
     let k = num_cpus::get() as u32; // render.rs:129: the 8-bit image depends on the slice count (render.rs:102-119)

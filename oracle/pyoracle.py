@@ -33,6 +33,9 @@ np.seterr(all="ignore")
 # a BVH node whose first child misses goes on to its other child (the dead src/bvh.rs:28-44), the slab test clips on all
 # three axes, a triangle rejects hits outside [t_min, t_max].  Set by the fixture generator and the tests, nowhere else.
 INTENDED = False
+# True: the second labelled alternative (RR_SEMANTICS_BOOK_ESTIMATOR): ray_color follows the ray a non-Lambertian material
+# scattered itself, weighted by the attenuation alone, and `lights` may be a list of XZRects.
+BOOK_ESTIMATOR = False
 
 
 def v3(x, y, z):
@@ -737,9 +740,49 @@ def _mul(a, b):
     return (a[0] * b[0], a[1] * b[1], a[2] * b[2])
 
 
+def _reflect(v, n):  # vec3.rs:268-270: v - n * 2 * dot(v, n)
+    return sub(v, scale(scale(n, f32(2)), dot(v, n)))
+
+
+def _refract(uv, n, etai_over_etat):  # vec3.rs:272-277
+    cos_theta = -min(dot(uv, n), f32(1))
+    perp = scale(add(uv, scale(n, cos_theta)), f32(etai_over_etat))
+    parallel = scale(n, -np.sqrt(abs(f32(1) - dot(perp, perp))))
+    return add(perp, parallel)
+
+
+def _reflectance(cosin, ref_idx):  # material.rs:116-120
+    r0 = (f32(1) - ref_idx) / (f32(1) + ref_idx)
+    r0 = r0 * r0
+    x = f32(1) - cosin
+    return r0 + (f32(1) - r0) * (x * x * x * x * x)
+
+
+def _lights(light):
+    """`light` as ray_color takes it -> list of members (None for a member that is no XZRect), or None for a single geometry."""
+    if isinstance(light, list):
+        return light
+    return None
+
+
+def _light_sample(light, origin, rnd):  # collider.rs:720-725, 400-403
+    if light is None:
+        return v3(1, 0, 0)
+    x = _stream_randrange(rnd, light[0], light[1])
+    z = _stream_randrange(rnd, light[2], light[3])
+    return sub((x, f32(light[4]), z), origin)
+
+
+def _light_pdf(light, origin, direction):  # collider.rs:714-719
+    if light is None:
+        return f32(0)
+    return xzrect_pdf_value(light[0], light[1], light[2], light[3], light[4], origin, direction)
+
+
 def ray_color(objects, materials, light, background, r, depth, bounce, key):
     """render.rs:15-41.  light = (x0, x1, z0, z1, k) of a bare XZRect passed as `lights`, or None for anything
-    else (pdf 0, sample (1,0,0): collider.rs:714-725).  key = (seed, pixel, sample)."""
+    else (pdf 0, sample (1,0,0): collider.rs:714-725); under BOOK_ESTIMATOR also a list of such members.
+    key = (seed, pixel, sample)."""
     if depth <= 0:
         return v3(0, 0, 0)
     rnd = PathStream(key[0], key[1], key[2], bounce)
@@ -749,38 +792,61 @@ def ray_color(objects, materials, light, background, r, depth, bounce, key):
     m = materials[rec.prim]
     kind = m[0]
     emitted = texture_color(m[1], rec.u, rec.v, rec.p) if kind == "emissive" else v3(0, 0, 0)  # material.rs:176-181
-    # scatter, material.rs:85-169: the scattered ray is overwritten at render.rs:32, so of each variant only the
-    # return value and the attenuation matter, and only the draws that can change those are taken
+    # scatter, material.rs:85-169: under the reference's semantics the scattered ray is overwritten at render.rs:32, so of
+    # each variant only the return value and the attenuation matter, and only the draws that can change those are taken;
+    # under BOOK_ESTIMATOR the ray of every material but the Lambertian is the one ray_color follows
+    sdir = None
     if kind == "lambertian":
         attenuation = texture_color(m[1], rec.u, rec.v, rec.p)
     elif kind == "glossy":
         ud = normalize(r.d)
-        reflected = sub(ud, scale(scale(rec.n, f32(2)), dot(ud, rec.n)))  # vec3.rs:268-270: v - n * 2 * dot(v, n)
+        reflected = _reflect(ud, rec.n)
         sd = add(reflected, scale(_random_in_unit_sphere(rnd), f32(m[2])))
         attenuation = v3(*m[1])
         if not (dot(sd, rec.n) > f32(0)):
             return emitted
+        sdir = sd
     elif kind == "dielectric":
         attenuation = v3(1, 1, 1)
+        if BOOK_ESTIMATOR:  # material.rs:128-148
+            ratio = f32(1) / f32(m[1]) if rec.front else f32(m[1])
+            ud = normalize(r.d)
+            cos_theta = min(dot(neg(ud), rec.n), f32(1))
+            sin_theta = np.sqrt(f32(1) - cos_theta * cos_theta)
+            if ratio * sin_theta > f32(1) or _reflectance(cos_theta, ratio) > rnd():
+                sdir = _reflect(ud, rec.n)
+            else:
+                sdir = _refract(ud, rec.n, ratio)
     elif kind == "isotropic":
+        if BOOK_ESTIMATOR:
+            sdir = _random_in_unit_sphere(rnd)  # material.rs:151 (before the texture lookup, which draws nothing)
         attenuation = texture_color(m[1], rec.u, rec.v, rec.p)
     else:
         return emitted
+    if BOOK_ESTIMATOR and kind != "lambertian":
+        li = ray_color(objects, materials, light, background, Ray(rec.p, sdir, r.tm), depth - 1, bounce + 1, key)
+        return add(emitted, _mul(attenuation, li))
     # render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal (pdf.rs:33-53)
     u, v, w = _onb(rec.n)
+    members = _lights(light) if BOOK_ESTIMATOR else None
     if rnd() < f32(0.5):
-        if light is not None:
-            x = _stream_randrange(rnd, light[0], light[1])
-            z = _stream_randrange(rnd, light[2], light[3])
-            direction = sub((x, f32(light[4]), z), rec.p)  # collider.rs:400-403
+        if members is not None:
+            k = min(int(rnd() * f32(len(members))), len(members) - 1)
+            direction = _light_sample(members[k], rec.p, rnd)
         else:
-            direction = v3(1, 0, 0)
+            direction = _light_sample(light, rec.p, rnd)
     else:
         cd = _random_cosine_direction(rnd)
         direction = add(add(scale(u, cd[0]), scale(v, cd[1])), scale(w, cd[2]))
     cosin = dot(normalize(direction), w)
     cos_pdf = f32(0) if cosin <= f32(0) else cosin / PI
-    light_pdf = xzrect_pdf_value(light[0], light[1], light[2], light[3], light[4], rec.p, direction) if light is not None else f32(0)
+    if members is not None:
+        weight = f32(1) / f32(len(members))
+        light_pdf = f32(0)
+        for mem in members:
+            light_pdf = light_pdf + weight * _light_pdf(mem, rec.p, direction)
+    else:
+        light_pdf = _light_pdf(light, rec.p, direction)
     with np.errstate(all="ignore"):
         pdf_val = f32(0.5) * light_pdf + f32(0.5) * cos_pdf
         sp = f32(0)  # material.rs:170-175

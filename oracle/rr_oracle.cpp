@@ -408,7 +408,7 @@ bool hit_instance(Ctx& c, const rr_instance& in, const Ray& r, float t_min, floa
 }
 
 bool hit_bvh(Ctx& c, const rr_bvh_node& nd, const Ray& r, float t_min, float t_max, Hit& out) {  // collider.rs:536-581
-    const bool intended = c.s->semantics == RR_SEMANTICS_INTENDED;
+    const bool intended = (c.s->semantics & RR_SEMANTICS_INTENDED) != 0u;
     if (nd.has_box) {
         if (c.cnt) c.cnt->box_tests++;
         if (!(intended ? aabb_hit_all_axes(nd.bmin, nd.bmax, r, t_min, t_max) : aabb_hit(nd.bmin, nd.bmax, r, t_min, t_max))) return false;
@@ -468,7 +468,7 @@ bool hit_ref(Ctx& c, uint32_t ref, const Ray& r, float t_min, float t_max, Hit& 
             return hit_rect(s.rects[idx], r, t_min, t_max, out);
         case RR_TAG_TRIANGLE:
             if (c.cnt) c.cnt->prim_tests++, c.cnt->tri_tests++;
-            return hit_triangle(s.triangles[idx], r, t_min, t_max, s.semantics == RR_SEMANTICS_INTENDED, out);
+            return hit_triangle(s.triangles[idx], r, t_min, t_max, (s.semantics & RR_SEMANTICS_INTENDED) != 0u, out);
         case RR_TAG_CUBOID:
             return hit_cuboid(c, s.cuboids[idx], r, t_min, t_max, out);
         case RR_TAG_MEDIUM:
@@ -571,10 +571,11 @@ float reflectance(float cosin, float ref_idx) {  // material.rs:116-120
     return r0 + (1.0f - r0) * x5;
 }
 
-// scatter (material.rs:85-169).  The scattered direction itself is dropped: ray_color
-// overwrites it with mixture.generate() (render.rs:32); what survives is the return
-// value, the attenuation, and the number of random draws consumed.
-bool scatter(const rr_flat_scene& s, const rr_material& m, const Ray& r_in, const Hit& rec, Philox& g, V3& attenuation) {
+// scatter (material.rs:85-169).  Under the reference's semantics the scattered direction itself is dropped: ray_color
+// overwrites it with mixture.generate() (render.rs:32); what survives is the return value, the attenuation, and the
+// number of random draws consumed.  `want_dir` (RR_SEMANTICS_BOOK_ESTIMATOR): the direction is what ray_color follows
+// for every material but the Lambertian, so it is formed, with the draws the reference's text takes for it.
+bool scatter(const rr_flat_scene& s, const rr_material& m, const Ray& r_in, const Hit& rec, Philox& g, V3& attenuation, bool want_dir, V3& sdir) {
     switch (m.type) {
         case RR_MAT_LAMBERTIAN: {
             // material.rs:85-92 draws a cosine direction here that render.rs:32 then overwrites.  Draws
@@ -588,15 +589,27 @@ bool scatter(const rr_flat_scene& s, const rr_material& m, const Ray& r_in, cons
             V3 reflected = reflect(unit(r_in.d), rec.n);
             V3 sd = reflected + random_in_unit_sphere(g) * m.param;
             attenuation = from(m.color);
+            sdir = sd;
             return dot(sd, rec.n) > 0.0f;
         }
         case RR_MAT_DIELECTRIC: {
-            // material.rs:128-148: reflect or refract by Schlick's approximation — into a direction that is
-            // discarded; what remains is attenuation 1 and `true`
+            // material.rs:128-148: reflect or refract by Schlick's approximation — into a direction that the reference's
+            // ray_color discards; what remains is attenuation 1 and `true`
             attenuation = mk(1, 1, 1);
+            if (want_dir) {
+                const float refraction_ratio = rec.front ? 1.0f / m.param : m.param;
+                const V3 unit_dir = unit(r_in.d);
+                const float cos_theta = std::fmin(dot(neg(unit_dir), rec.n), 1.0f);
+                const float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+                const bool cannot_refract = refraction_ratio * sin_theta > 1.0f;
+                // (`||` does not evaluate its right side, and so does not draw, when the left side holds)
+                if (cannot_refract || reflectance(cos_theta, refraction_ratio) > g.random()) sdir = reflect(unit_dir, rec.n);
+                else sdir = refract(unit_dir, rec.n, refraction_ratio);
+            }
             return true;
         }
         case RR_MAT_ISOTROPIC: {  // material.rs:150-154
+            if (want_dir) sdir = random_in_unit_sphere(g);
             attenuation = texture_color(s, m.texture, rec.u, rec.v, rec.p);
             return true;
         }
@@ -622,6 +635,21 @@ V3 light_random(const rr_light& l, V3 origin, Philox& g) {  // collider.rs:720-7
     float z = g.randrange(l.z0, l.z1);
     return mk(x, l.k, z) - origin;
 }
+// RR_SEMANTICS_BOOK_ESTIMATOR with `lights` a ColliderList: the mean of the members' pdf values, and the sample of one
+// member chosen uniformly (the reference's text has neither: collider.rs:714-725 gives a list pdf 0 and sample (1,0,0)).
+bool light_list(const rr_flat_scene& s) { return (s.semantics & RR_SEMANTICS_BOOK_ESTIMATOR) != 0u && s.n_lights != 0u; }
+float lights_pdf_value(const rr_flat_scene& s, V3 origin, V3 v) {
+    if (!light_list(s)) return light_pdf_value(s.light, origin, v);
+    const float weight = 1.0f / static_cast<float>(s.n_lights);
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < s.n_lights; ++i) sum += weight * light_pdf_value(s.lights[i], origin, v);
+    return sum;
+}
+V3 lights_random(const rr_flat_scene& s, V3 origin, Philox& g) {
+    if (!light_list(s)) return light_random(s.light, origin, g);
+    const uint32_t k = std::min(static_cast<uint32_t>(g.random() * static_cast<float>(s.n_lights)), s.n_lights - 1u);
+    return light_random(s.lights[k], origin, g);
+}
 
 // ---------------------------------------------------------------- render.rs
 struct PathKey {
@@ -640,15 +668,20 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
     if (!hit_children(c, s.child_refs + root.first_child, root.n_children, r, 0.001f, F32_MAX, rec)) return from(s.background);
     const rr_material& m = s.materials[rec.mat];
     V3 emitted = m.type == RR_MAT_EMISSIVE ? texture_color(s, m.texture, rec.u, rec.v, rec.p) : mk(0, 0, 0);  // material.rs:176-181
-    V3 attenuation = mk(0, 0, 0);
-    if (!scatter(s, m, r, rec, g, attenuation)) return emitted;
+    V3 attenuation = mk(0, 0, 0), sdir = mk(0, 0, 0);
+    const bool book = (s.semantics & RR_SEMANTICS_BOOK_ESTIMATOR) != 0u;
+    if (!scatter(s, m, r, rec, g, attenuation, book, sdir)) return emitted;
+    if (book && m.type != RR_MAT_LAMBERTIAN) {  // RR_SEMANTICS_BOOK_ESTIMATOR: a specular material's own ray, weighted by its attenuation alone
+        Ray specular{rec.p, sdir, r.tm};
+        return emitted + attenuation * ray_color(s, specular, depth - 1, bounce + 1, key, cnt);
+    }
     // render.rs:29-34
     ONB uvw = ONB::from_w(rec.n);
-    V3 dir = g.random() < 0.5f ? light_random(s.light, rec.p, g) : uvw.local(random_cosine_direction(g));  // pdf.rs:51-53
+    V3 dir = g.random() < 0.5f ? lights_random(s, rec.p, g) : uvw.local(random_cosine_direction(g));  // pdf.rs:51-53
     Ray scattered{rec.p, dir, r.tm};
     float cosin = dot(unit(dir), uvw.w);  // pdf.rs:33-36
     float cos_pdf = cosin <= 0.0f ? 0.0f : cosin / PI;
-    float pdf_val = 0.5f * light_pdf_value(s.light, rec.p, dir) + 0.5f * cos_pdf;  // pdf.rs:48-50
+    float pdf_val = 0.5f * lights_pdf_value(s, rec.p, dir) + 0.5f * cos_pdf;  // pdf.rs:48-50
     float sp = 0.0f;                                                              // material.rs:170-175
     if (m.type == RR_MAT_LAMBERTIAN) {                                            // material.rs:111-114
         float cs = dot(rec.n, unit(dir));

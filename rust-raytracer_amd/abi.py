@@ -31,7 +31,7 @@ NOALLOC_MAX_PATHS = 4194304
 EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
 SPLIT_SLICES, SPLIT_ROWS, SPLIT_BOTH = 0, 1, 2
 REDUCE_AUTO, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
-SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
+SEMANTICS_REFERENCE, SEMANTICS_INTENDED, SEMANTICS_BOOK_ESTIMATOR, SEMANTICS_BOOK = 0, 1, 2, 3
 
 
 def ref(tag, index):
@@ -125,7 +125,7 @@ class FlatScene(C.Structure):
                 _arr("child_refs", u32) + _arr("materials", Material) + _arr("textures", Texture) +
                 _arr("perlin", Perlin) + _arr("images", Image) +
                 [("n_image_bytes", u64), ("image_bytes", C.POINTER(u8)), ("root", u32), ("light", Light),
-                 ("camera", Camera), ("background", f32 * 3), ("semantics", u32)])
+                 ("camera", Camera), ("background", f32 * 3), ("semantics", u32), ("n_lights", u32), ("lights", C.POINTER(Light))])
 
 
 class RenderParams(C.Structure):

@@ -90,6 +90,8 @@ struct DevConst {
     const uint8_t* image_bytes;
     uint32_t light_is_xzrect;
     float light_x0, light_x1, light_z0, light_z1, light_k;
+    uint32_t n_lights;            // RR_SEMANTICS_BOOK_ESTIMATOR: members of the ColliderList passed as `lights` (0: the single light above)
+    const float4* lights;         // 2 per member: (x0, x1, z0, z1), (k, is_xzrect, -, -)
     rr_camera cam;
     float background[3];
 };
@@ -111,6 +113,7 @@ struct DevScene {  // kernel argument
     uint32_t n_ops;                 // ops before the terminating OP_ENDs
     float cull_eps, cull_k;         // boxes are grown by cull_eps + cull_k * distance^2 in the culling test
     uint32_t intended;              // RR_SEMANTICS_INTENDED: the labelled alternative semantics (see include/rr_hip.h), 0 by default
+    uint32_t book;                  // RR_SEMANTICS_BOOK_ESTIMATOR: specular materials keep their own ray, `lights` may be a list; 0 by default
     uint32_t lean;                  // like no_tri: 1 in the kernels the host launches only for scenes whose media are all bounded by a
                                     // bare sphere (no OP_MED_BEGIN / MID / END), whose cuboids are all the constructor's and whose
                                     // instances nest at most two deep
@@ -1915,18 +1918,52 @@ __device__ __forceinline__ float reflectance(float cosin, float ref_idx) {  // m
     return r0 + (1.0f - r0) * (x * x * x * x * x);
 }
 
-__device__ __forceinline__ float light_pdf_value(const DevScene& sc, f3 origin, f3 v) {  // collider.rs:389-399, 714-719
-    if (!sc.k->light_is_xzrect) return 0.0f;
+// Geometry::pdf_value of a bare XZRect (collider.rs:389-399, 714-719); anything else has pdf 0.
+__device__ __forceinline__ float xzrect_pdf_value(bool is_xzrect, float x0, float x1, float z0, float z1, float k, f3 origin, f3 v) {
+    if (!is_xzrect) return 0.0f;
     float t, ca, cb;
-    if (!test_rect(make_float4(sc.k->light_x0, sc.k->light_x1, sc.k->light_z0, sc.k->light_z1), sc.k->light_k, RR_RECT_XZ, origin, v, 0.001f,
-                   kF32Max, t, ca, cb))
-        return 0.0f;
+    if (!test_rect(make_float4(x0, x1, z0, z1), k, RR_RECT_XZ, origin, v, 0.001f, kF32Max, t, ca, cb)) return 0.0f;
     const f3 outn = mk3(0.0f, 1.0f, 0.0f);
     const f3 n = dot3(v, outn) < 0.0f ? outn : neg3(outn);
-    const float area = (sc.k->light_x1 - sc.k->light_x0) * (sc.k->light_z1 - sc.k->light_z0);
+    const float area = (x1 - x0) * (z1 - z0);
     const float dist_sqrd = t * t * len2(v);
     const float cosine = fabsf(dot3(v, n) / len3(v));
     return dist_sqrd / (cosine * area);
+}
+__device__ __forceinline__ float light_pdf_value(const DevScene& sc, f3 origin, f3 v) {
+    if (sc.book && sc.k->n_lights != 0u) {  // the labelled book estimator with a list of lights: the mean of the members' values
+        const uint32_t n = sc.k->n_lights;
+        const float weight = 1.0f / static_cast<float>(n);
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float4 a = sc.k->lights[2 * i], b = sc.k->lights[2 * i + 1];
+            sum += weight * xzrect_pdf_value(__float_as_uint(b.y) != 0u, a.x, a.y, a.z, a.w, b.x, origin, v);
+        }
+        return sum;
+    }
+    return xzrect_pdf_value(sc.k->light_is_xzrect != 0u, sc.k->light_x0, sc.k->light_x1, sc.k->light_z0, sc.k->light_z1, sc.k->light_k, origin, v);
+}
+// Geometry::random (collider.rs:400-403, 720-725): towards a uniform point of a bare XZRect; (1,0,0) for anything else.
+__device__ __forceinline__ f3 light_random(const DevScene& sc, f3 origin, Rng& g) {
+    bool is_xz = sc.k->light_is_xzrect != 0u;
+    float x0 = sc.k->light_x0, x1 = sc.k->light_x1, z0 = sc.k->light_z0, z1 = sc.k->light_z1, k = sc.k->light_k;
+    if (sc.book && sc.k->n_lights != 0u) {  // one member of the list, chosen uniformly
+        const uint32_t n = sc.k->n_lights;
+        const uint32_t i = min(static_cast<uint32_t>(g.random() * static_cast<float>(n)), n - 1u);
+        const float4 a = sc.k->lights[2 * i], b = sc.k->lights[2 * i + 1];
+        is_xz = __float_as_uint(b.y) != 0u;
+        x0 = a.x, x1 = a.y, z0 = a.z, z1 = a.w, k = b.x;
+    }
+    if (!is_xz) return mk3(1.0f, 0.0f, 0.0f);
+    const float x = g.randrange(x0, x1);
+    const float z = g.randrange(z0, z1);
+    return mk3(x, k, z) - origin;
+}
+__device__ __forceinline__ f3 refract3(f3 uv, f3 n, float etai_over_etat) {  // vec3.rs:272-277
+    const float cos_theta = -fminf(dot3(uv, n), 1.0f);
+    const f3 perp = (uv + n * cos_theta) * etai_over_etat;
+    const f3 parallel = n * -(sqrtf(fabsf(1.0f - len2(perp))));
+    return perp + parallel;
 }
 
 // One ray_color call (render.rs:15-41) minus the recursion.  Returns true when the
@@ -1952,7 +1989,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     const DevMaterial m = sc.k->materials[meta.mat];
     const HitRec rec = FETCHED ? reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, r0, r1, sc.k->images != nullptr)
                                : reconstruct_hit<EAGER_CHAIN>(sc, wo, wd, time, t, ref, meta, sc.k->images != nullptr);
-    f3 attenuation;
+    f3 attenuation, sdir = mk3(0.0f, 0.0f, 0.0f);
     const f3 own = mk3(m.r, m.g, m.b);
     if (m.type == RR_MAT_EMISSIVE) {  // material.rs:156-158, 176-181
         out.value = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
@@ -1972,10 +2009,27 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
             out.value = mk3(0.0f, 0.0f, 0.0f);
             return false;
         }
+        sdir = sd;
     } else if (m.type == RR_MAT_DIELECTRIC) {  // material.rs:128-148: always scatters, attenuation 1
         attenuation = mk3(1.0f, 1.0f, 1.0f);
+        if (sc.book) {  // (the direction the reference's ray_color throws away)
+            const float ratio = rec.front ? 1.0f / m.param : m.param;
+            const f3 ud = unit3(wd);
+            const float cos_theta = fminf(dot3(neg3(ud), rec.n), 1.0f);
+            const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            // (`||` does not evaluate its right side, and so does not draw, when the left side holds)
+            if (ratio * sin_theta > 1.0f || reflectance(cos_theta, ratio) > g.random()) sdir = ud - rec.n * 2.0f * dot3(ud, rec.n);
+            else sdir = refract3(ud, rec.n, ratio);
+        }
     } else {  // isotropic, material.rs:150-154
+        if (sc.book) sdir = random_in_unit_sphere(g);
         attenuation = m.solid ? own : texture_color(sc, m.texture, rec.u, rec.v, rec.p);
+    }
+    if (sc.book && m.type != RR_MAT_LAMBERTIAN) {  // RR_SEMANTICS_BOOK_ESTIMATOR: a specular material's own ray, weighted by its attenuation alone
+        out.o = rec.p;
+        out.d = sdir;
+        out.value = attenuation;
+        return true;
     }
     // render.rs:29-33: mixture of the light pdf and the cosine pdf about the hit normal
     const f3 w = unit3(rec.n);  // vec3.rs:205-215
@@ -1984,13 +2038,7 @@ __device__ __forceinline__ bool shade(const DevScene& sc, f3 wo, f3 wd, float ti
     const f3 u = cross3(w, v);
     f3 dir;
     if (g.random() < 0.5f) {  // pdf.rs:51-53 → collider.rs:400-403 / 720-725
-        if (sc.k->light_is_xzrect) {
-            const float x = g.randrange(sc.k->light_x0, sc.k->light_x1);
-            const float z = g.randrange(sc.k->light_z0, sc.k->light_z1);
-            dir = mk3(x, sc.k->light_k, z) - rec.p;
-        } else {
-            dir = mk3(1.0f, 0.0f, 0.0f);
-        }
+        dir = light_random(sc, rec.p, g);
     } else {
         const f3 cd = random_cosine_direction(g);
         dir = u * cd.x + v * cd.y + w * cd.z;

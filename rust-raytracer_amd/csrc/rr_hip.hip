@@ -908,7 +908,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + RR_WF_TRAVERSE_EXTRA_LDS;
     using TraverseKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, uint32_t, unsigned long long*);
     using FinishKernel = void (*)(DevScene, WfArgs, WfState, const uint32_t*, WfCtl*, unsigned long long*);
-    const bool ref_sem = ctx->sc.intended == 0u;  // (the production kernels have a build that knows the semantics switch is off)
+    const bool ref_sem = ctx->sc.intended == 0u && ctx->sc.book == 0u;  // (the production kernels have a build that knows the semantics switches are off)
     const bool wide = ctx->wide_scene && !(flags & RR_FLAG_NARROW_NODES);  // (a wide scene has the reference's semantics and no general subtrees)
     const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? (wide ? k_wf_traverse<COUNT_PRODUCTION, false, true> : k_wf_traverse<COUNT_PRODUCTION>)
                                       : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE>
@@ -1025,7 +1025,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and for lean scenes
     // (rr_context::lean_scene) the builds at 5 waves per SIMD instead of 4 that leave out what such scenes do not need (see k_wf_paths).
     constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
-    const bool ref_sem = ctx->sc.intended == 0u, w5 = ctx->lean_scene && !ctx->has_triangles;
+    const bool ref_sem = ctx->sc.intended == 0u && ctx->sc.book == 0u, w5 = ctx->lean_scene && !ctx->has_triangles;
     PathsKernel kernel;
     if (ctx->has_subtrees) {
         if (count == COUNT_PRODUCTION) kernel = k_wf_paths<COUNT_PRODUCTION, true, true>;
@@ -1042,9 +1042,14 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
         // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
         // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
     } else if (ctx->prog_vector_ops) {
-        kernel = count ? k_wf_paths<COUNT_REFERENCE, true> : w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, true>;
+        // (without subtrees REF_SEM only concerns shading: the builds that know the book estimator is off do not carry its code)
+        if (count) kernel = k_wf_paths<COUNT_REFERENCE, true>;
+        else if (ref_sem) kernel = w5 ? k_wf_paths<COUNT_OFF, true, false, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, false, true, true>;
+        else kernel = w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, true>;
     } else {
-        kernel = count ? k_wf_paths<COUNT_REFERENCE, false> : w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, false>;
+        if (count) kernel = k_wf_paths<COUNT_REFERENCE, false>;
+        else if (ref_sem) kernel = w5 ? k_wf_paths<COUNT_OFF, false, false, true, true, W5, true> : k_wf_paths<COUNT_OFF, false, false, true, true>;
+        else kernel = w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, false>;
     }
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + (ctx->has_subtrees ? 4u * PARK_LDS_WORDS_PER_WAVE * 4u : 0u);
@@ -1185,7 +1190,9 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     if ((s->n_child_refs && !s->child_refs) || (s->n_materials && !s->materials) || (s->n_textures && !s->textures) ||
         (s->n_perlin && !s->perlin) || (s->n_images && !s->images) || (s->n_image_bytes && !s->image_bytes))
         return fail(RR_E_INVALID, "rr_scene_upload: a non-empty array has a NULL pointer");
-    if (s->semantics > RR_SEMANTICS_INTENDED) return fail(RR_E_INVALID, "rr_scene_upload: unknown semantics");
+    if (s->semantics > RR_SEMANTICS_BOOK) return fail(RR_E_INVALID, "rr_scene_upload: unknown semantics");
+    const bool sem_intended = (s->semantics & RR_SEMANTICS_INTENDED) != 0u, sem_book = (s->semantics & RR_SEMANTICS_BOOK_ESTIMATOR) != 0u;
+    if (sem_book && s->n_lights != 0u && !s->lights) return fail(RR_E_INVALID, "rr_scene_upload: n_lights without lights");
     if (RR_REF_TAG(s->root) != RR_TAG_LIST || RR_REF_INDEX(s->root) >= s->n_lists)
         return fail(RR_E_INVALID, "rr_scene_upload: root must be a list ref");
     for (uint32_t i = 0; i < s->n_materials; ++i) {
@@ -1260,7 +1267,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
                 holds = static_cast<double>(n.bmin[a]) - 0.5 * cull_eps <= b.lo[a] && b.hi[a] <= static_cast<double>(n.bmax[a]) + 0.5 * cull_eps;
             if (holds) cls = b.has_tri ? BVH_CLASS_CULL_ANY_T : BVH_CLASS_CULL_RANGE;
             // under the labelled intended semantics the class only says whether a repeated visit could draw random numbers
-            if (s->semantics == RR_SEMANTICS_INTENDED) cls = b.has_medium ? BVH_CLASS_REFERENCE : BVH_CLASS_CULL_RANGE;
+            if (sem_intended) cls = b.has_medium ? BVH_CLASS_REFERENCE : BVH_CLASS_CULL_RANGE;
         }
         bvh[2 * i + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], u2f(to_dref(n.right, cls)));
         bvh_class[i] = static_cast<uint8_t>(cls);
@@ -1270,7 +1277,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // from one 64-byte record of the node.  It is for scenes under the reference's semantics in which every BVH node of the
     // tree is of a culling class and has nothing but BVH nodes, spheres, rects, triangles and cuboids below it; such scenes
     // get the records when they are ones the pipeline renders, the others keep the one-box-per-visit moves.
-    bool wide_scene = s->semantics != RR_SEMANTICS_INTENDED && s->n_bvh_nodes != 0;
+    bool wide_scene = !sem_intended && s->n_bvh_nodes != 0;
     for (uint32_t i = 0; i < s->n_bvh_nodes && wide_scene; ++i)
         if (wk.seen[RR_TAG_BVH][i])
             wide_scene = bvh_class[i] >= BVH_CLASS_CULL_RANGE && wk.bvh_below[i].simple;
@@ -1410,6 +1417,13 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     std::vector<DevImage> images(s->n_images);
     for (uint32_t i = 0; i < s->n_images; ++i) images[i] = DevImage{s->images[i].width, s->images[i].height, s->images[i].offset};
     std::vector<uint8_t> image_bytes(s->image_bytes, s->image_bytes + s->n_image_bytes);
+    std::vector<float4> light_list;  // (read by the book estimator only)
+    if (sem_book)
+        for (uint32_t i = 0; i < s->n_lights; ++i) {
+            const rr_light& l = s->lights[i];
+            light_list.push_back(make_float4(l.x0, l.x1, l.z0, l.z1));
+            light_list.push_back(make_float4(l.k, u2f(l.is_xzrect ? 1u : 0u), 0.f, 0.f));
+        }
     ProgramBuilder pb{*s, wk.bvh_below, bvh_class, {}, {}, {}, false, !ctx->sw_no_fuse};
     pb.emit(s->root);
     if (pb.fuse) pb.fuse_transforms();
@@ -1448,7 +1462,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
         (rc = upload(mem, child_refs, &d.child_refs)) || (rc = upload(mem, materials, &k.materials)) ||
         (rc = upload(mem, textures, &k.textures)) || (rc = upload(mem, perlin_vec, &k.perlin_vec)) ||
         (rc = upload(mem, perlin_perm, &k.perlin_perm)) || (rc = upload(mem, images, &k.images)) ||
-        (rc = upload(mem, image_bytes, &k.image_bytes)) || (rc = upload(mem, prog, &prog_dev))) {
+        (rc = upload(mem, image_bytes, &k.image_bytes)) || (rc = upload(mem, light_list, &k.lights)) || (rc = upload(mem, prog, &prog_dev))) {
         mem.release();
         return rc;
     }
@@ -1460,6 +1474,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     k.light_z0 = s->light.z0;
     k.light_z1 = s->light.z1;
     k.light_k = s->light.k;
+    k.n_lights = static_cast<uint32_t>(light_list.size() / 2);
     k.cam = s->camera;
     for (int a = 0; a < 3; ++a) k.background[a] = s->background[a];
     const DevConst* k_dev = nullptr;
@@ -1513,7 +1528,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
                                     " bytes of LDS available to one workgroup");
     }
     ctx->root = to_dref(s->root);
-    ctx->sc.intended = s->semantics == RR_SEMANTICS_INTENDED ? 1u : 0u;
+    ctx->sc.intended = sem_intended ? 1u : 0u;
+    ctx->sc.book = sem_book ? 1u : 0u;
     ctx->sc.no_tri = ctx->sc.lean = 0u;
     ctx->sc.cull_eps = static_cast<float>(cull_eps);
     ctx->sc.cull_k = static_cast<float>(std::min(cull_k, 1e30));  // a zero radius leaves a margin no box is missed by

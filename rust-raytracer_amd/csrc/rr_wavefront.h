@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     // REF_SEM: a build that is only launched for scenes with the reference's own semantics, so that the switch is a constant
     // to the compiler and not a scalar register (and a lane mask per clipping axis) held through the traversal loops.
     DevScene sc = sc_arg;
-    if (REF_SEM) sc.intended = 0u;
+    if (REF_SEM) sc.intended = 0u, sc.book = 0u;
     // (the host launches the lean builds only for scenes without media that are not bounded by a bare sphere, without cuboids
     // that are not the constructor's and with instances at most two deep, and those with more waves only if the scene has no
     // triangles either: that code, and the registers it needs, is not in them)
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     k_wf_traverse(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
                   unsigned long long* counters) {
     DevScene sc = sc_arg;
-    if (REF_SEM) sc.intended = 0u;
+    if (REF_SEM) sc.intended = 0u, sc.book = 0u;
     sc.no_tri = sc.lean = 0u;
     extern __shared__ uint32_t lds_stack[];
     uint32_t* stk = lds_stack + threadIdx.x;
@@ -570,7 +570,7 @@ template <int COUNT, bool GENERAL = true, bool REF_SEM = false>  // GENERAL = fa
 __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue,
                                                                                 WfCtl* ctl, unsigned long long* counters) {
     DevScene sc = sc_arg;
-    if (REF_SEM) sc.intended = 0u;
+    if (REF_SEM) sc.intended = 0u, sc.book = 0u;
     sc.no_tri = sc.lean = 0u;
     own_registers(sc);
     extern __shared__ uint32_t lds_stack[];

@@ -222,15 +222,22 @@ std::unique_ptr<FlatScene> flatten(const SceneColliders& scene, const GeometryPt
     }
 
     // collider.rs:714-725: only a bare XZRect has pdf_value/random.
-    fs->light = rr_light{};
-    if (lights && lights->type == GeometryType::XZRect) {
-        fs->light.is_xzrect = 1;
-        fs->light.x0 = lights->f[0];
-        fs->light.x1 = lights->f[1];
-        fs->light.z0 = lights->f[2];
-        fs->light.z1 = lights->f[3];
-        fs->light.k = lights->f[4];
-    }
+    auto as_light = [](const GeometryPtr& g) {
+        rr_light l{};
+        if (g && g->type == GeometryType::XZRect) {
+            l.is_xzrect = 1;
+            l.x0 = g->f[0];
+            l.x1 = g->f[1];
+            l.z0 = g->f[2];
+            l.z1 = g->f[3];
+            l.k = g->f[4];
+        }
+        return l;
+    };
+    fs->light = as_light(lights);
+    // (the members of a ColliderList passed as `lights`: the book estimator's light list, unread under the reference's semantics)
+    if (lights && lights->type == GeometryType::ColliderList)
+        for (const GeometryPtr& member : lights->children) fs->lights.push_back(as_light(member));
 
     rr_camera& c = fs->camera;
     for (int a = 0; a < 3; ++a) {
@@ -284,6 +291,8 @@ rr_flat_scene FlatScene::view() const {
     v.image_bytes = image_bytes.data();
     v.root = root;
     v.light = light;
+    v.n_lights = static_cast<uint32_t>(lights.size());
+    v.lights = lights.empty() ? nullptr : lights.data();
     v.camera = camera;
     v.background[0] = background[0];
     v.background[1] = background[1];

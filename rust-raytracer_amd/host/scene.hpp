@@ -283,6 +283,7 @@ class FlatScene {
     std::vector<uint8_t> image_bytes;
     uint32_t root = RR_REF_NONE;
     rr_light light{};
+    std::vector<rr_light> lights;  // the members of `lights` when it is a ColliderList (read under RR_SEMANTICS_BOOK_ESTIMATOR only)
     rr_camera camera{};
     float background[3] = {0, 0, 0};
     uint32_t n_prims = 0;

@@ -82,13 +82,26 @@ def make_paths():
           f"{np.isnan(nolight).any(axis=-1).mean():.2f} of the samples are NaN; {time.time() - t0:.1f} s")
 
 
+def make_paths_book():
+    """The same scene under the labelled book semantics (RR_SEMANTICS_BOOK): specular materials keep their own ray, `lights`
+    is a list (golden_paths.LIGHT_LIST), the traversal is the intended one."""
+    import golden_paths as GP
+    t0 = time.time()
+    samples = GP.render_py(book=True)
+    np.savez_compressed(os.path.join(HERE, "paths_box_book.npz"), samples=samples, **{k: np.asarray(v) for k, v in GP.RENDER.items()})
+    print(f"paths_box_book: {samples.shape[0] * samples.shape[1] * samples.shape[2]} samples, mean {np.nanmean(samples):.4f}, "
+          f"{np.isnan(samples).any(axis=-1).mean():.3f} NaN; {time.time() - t0:.1f} s")
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(G.SCENES) + [n + "_intended" for n in G.INTENDED_SCENES] + ["perlin", "paths"]
+    names = sys.argv[1:] or list(G.SCENES) + [n + "_intended" for n in G.INTENDED_SCENES] + ["perlin", "paths", "paths_book"]
     for nm in names:
         if nm == "perlin":
             make_perlin()
         elif nm == "paths":
             make_paths()
+        elif nm == "paths_book":
+            make_paths_book()
         elif nm.endswith("_intended"):
             make_scene(nm[:-len("_intended")], intended=True)
         else:

@@ -8,6 +8,9 @@ RENDER = dict(W=24, H=20, spp=8, max_depth=12, seed=5)   # 8 slices of one sampl
 CAM = dict(look_from=(278, 278, -800), look_at=(278, 278, 0), vup=(0, 1, 0), vfov=40.0, aperture=12.0, focus_dist=800.0,
            aspect=1.2)
 LIGHT = (163.0, 393.0, 177.0, 382.0, 554.0)  # x0, x1, z0, z1, k of the XZRect passed as `lights`
+# `lights` of the render under the labelled book estimator (RR_SEMANTICS_BOOK): a ColliderList of the lamp, a second XZRect
+# next to it (not part of the scene: sampling it finds whatever lies that way) and a sphere (no XZRect: pdf 0, sample (1,0,0))
+LIGHT_LIST = [LIGHT, (60.0, 140.0, 400.0, 480.0, 554.0), None]
 BACKGROUND = (0.02, 0.03, 0.05)
 IMAGE = (np.arange(4 * 5 * 3, dtype=np.uint32).reshape(4, 5, 3) * 37 % 256).astype(np.uint8)
 
@@ -41,9 +44,10 @@ def build_py():
     return objs, P.materials_by_prim(objs), cam
 
 
-def build_host(light=True):
+def build_host(light=True, book=False):
     """light=False: an empty list is passed as `lights` (as random_spheres does, main.rs:111): its pdf is 0 and its
-    sample (1,0,0), so many samples are 0/0 = NaN (render.rs:34)."""
+    sample (1,0,0), so many samples are 0/0 = NaN (render.rs:34).  book=True: LIGHT_LIST is passed, and the flattened
+    scene asks for RR_SEMANTICS_BOOK."""
     import rust_raytracer_amd  # noqa: F401
     from rust_raytracer_amd import host
     b = host.SceneBuilder(SEED)
@@ -62,20 +66,40 @@ def build_host(light=True):
               b.moving_sphere((100, 400, 200), (130, 400, 200), 0.0, 1.0, 50.0, lam((0.7, 0.3, 0.1))),
               b.bvh_node(small, 0.0, 1.0)]:
         b.add(g)
-    b.set_lights(b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0))) if light else b.collider_list([]))
+    if book:
+        em = b.emissive((15.0, 15.0, 15.0))
+        b.set_lights(b.collider_list([b.xzrect(*m, em) if m is not None else b.sphere((278, 300, 278), 40.0, em) for m in LIGHT_LIST]))
+    else:
+        b.set_lights(b.xzrect(*LIGHT, b.emissive((15.0, 15.0, 15.0))) if light else b.collider_list([]))
     b.set_camera(CAM["look_from"], CAM["look_at"], CAM["vup"], CAM["vfov"], CAM["aperture"], CAM["focus_dist"], CAM["aspect"], 0.0, 1.0)
     b.set_background(BACKGROUND)
-    return b, b.flatten()
+    flat = b.flatten()
+    if book:
+        from rust_raytracer_amd import abi
+        flat.semantics = abi.SEMANTICS_BOOK
+    return b, flat
 
 
 NOLIGHT = dict(W=16, H=12, spp=4)  # the second, smaller render: same scene, empty `lights`
 
 
-def render_py(light=True):
+def render_py(light=True, book=False):
     """→ float32 [spp, H, W, 3]: the radiance of every sample, laid out like the per-slice sums of a render with one
-    sample per slice."""
+    sample per slice.  book=True: under RR_SEMANTICS_BOOK (intended traversal + book estimator) with LIGHT_LIST as `lights`."""
     import pyoracle as P
     objs, mats, cam = build_py()
+    if book:
+        P.INTENDED = P.BOOK_ESTIMATOR = True
+        try:
+            W, H, spp = RENDER["W"], RENDER["H"], RENDER["spp"]
+            out = np.zeros((spp, H, W, 3), dtype=np.float32)
+            for s in range(spp):
+                for row in range(H):
+                    for i in range(W):
+                        out[s, row, i] = P.sample_pixel(objs, mats, list(LIGHT_LIST), BACKGROUND, cam, W, H, i, row, s, RENDER["max_depth"], RENDER["seed"])
+            return out
+        finally:
+            P.INTENDED = P.BOOK_ESTIMATOR = False
     W, H, spp = (RENDER if light else NOLIGHT)["W"], (RENDER if light else NOLIGHT)["H"], (RENDER if light else NOLIGHT)["spp"]
     out = np.zeros((spp, H, W, 3), dtype=np.float32)
     for s in range(spp):

@@ -139,6 +139,27 @@ def test_cpp_oracle_paths_match_the_numpy_restatement(built):
     assert (gold[both] != 0).mean() > 0.5
 
 
+def test_cpp_oracle_paths_under_the_book_semantics_match_the_numpy_restatement(built):
+    """RR_SEMANTICS_BOOK (never the default: specular materials keep the ray they scattered, `lights` is a list, the
+    traversal is the intended one), restated twice like the reference's own semantics: the C++ oracle against pyoracle's
+    fixture, sample by sample; and it is a different image from the reference's (glass, metal and smoke carry light)."""
+    import golden_paths as GP
+    fx = np.load(os.path.join(G.GOLDEN_DIR, "paths_box_book.npz"))
+    assert all(int(fx[k]) == v for k, v in GP.RENDER.items()), "fixture is stale: python tests/golden/make_golden.py paths_book"
+    gold = fx["samples"]
+    b, flat = GP.build_host(book=True)
+    assert flat.n_lights == 3 and flat.lights[0].is_xzrect == 1 and flat.lights[2].is_xzrect == 0
+    R = GP.RENDER
+    p = O.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    got = O.render(flat, p, n_threads=4)["slice_sums"]
+    compare_samples(got, gold, 0.99)
+    both = ~np.isnan(got) & ~np.isnan(gold)
+    assert (got[both] == gold[both]).mean() > 0.9
+    _, ref = _paths_fixture()
+    finite = ~np.isnan(gold) & ~np.isnan(ref)
+    assert (gold[finite] != ref[finite]).mean() > 0.3 and np.nanmean(gold) > 1.2 * np.nanmean(ref)
+
+
 def test_cpp_oracle_nan_samples_match_the_numpy_restatement(built):
     """The same scene with an empty list as `lights` (pdf 0, sample (1,0,0), collider.rs:714-725): which samples come out
     as 0/0 = NaN (render.rs:34) and what the others are."""

@@ -1050,6 +1050,39 @@ def test_config5_at_full_size(gpu_ctx):
         assert other["counters"]["rays"] == small["counters"]["rays"]
 
 
+# ------------------------------------------------- the labelled book estimator
+def test_book_semantics_match_the_fixture_the_oracle_and_every_kernel_form(gpu_ctx):
+    """RR_SEMANTICS_BOOK (never the default): specular materials keep the ray they scattered, `lights` is a list of three
+    members, the traversal is the intended one.  The device against pyoracle's fixture and against the C++ oracle sample
+    by sample, every kernel organisation the same bits, and the list of lights against a single light."""
+    import golden_paths as GP
+    from test_golden_cpu import compare_samples
+    fx = np.load(f"{G.GOLDEN_DIR}/paths_box_book.npz")
+    b, flat = GP.build_host(book=True)
+    info = gpu_ctx.upload(flat)
+    R = GP.RENDER
+    kw = dict(n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    got = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], **kw))
+    compare_samples(got["slice_sums"], fx["samples"], 0.985)
+    want = O.render(flat, O.make_params(R["W"], R["H"], R["spp"], **kw), n_threads=8, counters=True)
+    compare_samples(got["slice_sums"], want["slice_sums"], 0.985)
+    assert abs(got["counters"]["rays"] - want["counters"]["rays"]) < 0.01 * want["counters"]["rays"]
+    for flags in (abi.FLAG_PATHS, abi.FLAG_PERSISTENT, abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_COUNTERS):
+        other = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], flags=flags, **kw))
+        assert np.array_equal(got["slice_sums"], other["slice_sums"], equal_nan=True), flags
+    # a larger render of the same scene: the device against the oracle, and not the image of the reference's semantics
+    big = dict(n_slices=4, max_depth=20, seed=8)
+    a = gpu_ctx.render(device.make_params(96, 80, 16, **big))
+    o = O.render(flat, O.make_params(96, 80, 16, **big), n_threads=16)
+    both = ~np.isnan(a["slice_sums"]) & ~np.isnan(o["slice_sums"])
+    assert (np.isnan(a["slice_sums"]) == np.isnan(o["slice_sums"])).mean() > 0.995 and both.mean() > 0.3
+    assert np.isclose(a["slice_sums"][both], o["slice_sums"][both], rtol=1e-3, atol=1e-4).mean() > 0.97
+    b2, flat2 = GP.build_host()
+    gpu_ctx.upload(flat2)
+    ref = gpu_ctx.render(device.make_params(96, 80, 16, **big))
+    assert np.nanmean(a["slice_sums"]) > 1.2 * np.nanmean(ref["slice_sums"])  # glass, metal and smoke carry light now
+
+
 # ------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("W,H", [(2, 2), (37, 21), (8, 8), (65, 9)])
 def test_odd_image_sizes(gpu_ctx, W, H):

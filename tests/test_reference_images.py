@@ -100,3 +100,44 @@ def test_device_cornell_box_matches_the_images_the_reference_holds(built, gpu_ct
     dist = check_against_reference_images(r["rgb8"], f"device K={n_slices} {spp} spp")
     for n in MATCH:  # at these sample counts the device is as close to a reference run as the two reference runs are to each other
         assert dist[n][0] <= 0.012, (n, dist[n])
+
+
+# ------------------------------------------------------------------------------------------ the labelled book semantics
+def _book_scene(name, **kw):
+    from rust_raytracer_amd import abi, host
+    b, flat, d = host.build_config_scene(name, **kw)
+    flat.semantics = abi.SEMANTICS_BOOK
+    return b, flat, d
+
+
+@pytest.mark.gpu
+def test_book_semantics_render_the_other_images_the_reference_holds(built, gpu_ctx):
+    """`output/suzanne.png` and `output/final_scene.png` of the reference were rendered by earlier revisions: the light is
+    part of the scene, metal, glass and smoke carry light, the whole BVH is visible.  HEAD renders neither (black: the light
+    is not in the scene, main.rs:451,513-514; and with it added, every non-Lambertian surface stays black, material.rs:170-175).
+    RR_SEMANTICS_BOOK (never the default: intended traversal + the book's estimator) on the scenes of main.rs:416-464 and
+    :466-541 with the light added renders what final_scene.png shows.  A weak pin: the random box heights and the random
+    sphere cluster differ from the run that made the image, so the thresholds are loose — and still far from what the
+    reference's own semantics give on the same scene."""
+    from rust_raytracer_amd import abi, device
+    results = {}
+    for name, png, side, depth, kw in (("suzanne", "suzanne", 600, 100, {}), ("final", "final_scene", 800, 50, dict(moving_sphere=False))):
+        ref = load_png(png)
+        for sem in ("book", "reference"):
+            b, flat, d = _book_scene(name, **kw)
+            if sem == "reference":
+                flat.semantics = abi.SEMANTICS_REFERENCE
+            gpu_ctx.upload(flat)
+            r = gpu_ctx.render(device.make_params(side, side, 512, n_slices=8, max_depth=depth, seed=3), slice_sums=False)
+            results[(name, sem)] = distance(r["rgb8"].astype(np.float64), ref)
+            rmse, mean_rel, corr = results[(name, sem)]
+            print(f"{name} under {sem} semantics vs {png}.png: rmse/255 {rmse:.4f}, channel means within {100 * mean_rel:.1f} %, correlation {corr:.4f}")
+    # final_scene.png (measured: rmse/255 0.105, channel means within 1.3 %, correlation 0.907; under the reference's own
+    # semantics 0.218, 51 %, 0.804: glass, metal, smoke and most of the BVHs are missing there)
+    rmse, mean_rel, corr = results[("final", "book")]
+    assert rmse <= 0.13 and mean_rel <= 0.05 and corr >= 0.88
+    assert results[("final", "reference")][0] > 1.7 * rmse and results[("final", "reference")][1] > 0.3
+    # suzanne.png pins no more than the camera and the room: the revision that made it had a far brighter light than the
+    # (2, 2, 2) of main.rs:447 (its walls are saturated: channel means 55 % above any render of the scene as HEAD has it) and
+    # a reflecting Suzanne where HEAD's is white Lambertian (main.rs:459), so neither semantics is nearer to it than the other
+    assert results[("suzanne", "book")][2] >= 0.75 and results[("suzanne", "reference")][2] >= 0.75
