@@ -191,8 +191,11 @@ def parse_args(argv=None):
                     help="default: slices when N divides K (every GPU the same samples of the whole image: balanced), rows otherwise")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--flags", type=int, default=0, help="RR_FLAG_* bits for the timed renders (kernel organisation)")
-    ap.add_argument("--semantics", default="reference", choices=["reference", "intended"],
-                    help="intended: the labelled alternative semantics (RR_SEMANTICS_INTENDED), never the default")
+    ap.add_argument("--semantics", default="reference", choices=["reference", "intended", "book"],
+                    help="intended / book: the labelled alternative semantics (RR_SEMANTICS_INTENDED, RR_SEMANTICS_BOOK), never the default")
+    ap.add_argument("--bvh", default="reference", choices=["reference", "sah"],
+                    help="sah: every BVH of the scene is a surface-area-heuristic tree, NOT the reference's (a labelled option for "
+                         "--semantics intended: what the reference's tree costs next to a conventional one)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting passes")
     ap.add_argument("--no-weak", action="store_true", help="with N > 1: skip the second (weak-scaling) measurement")
@@ -281,9 +284,11 @@ def load_scene(args):
     scene_name, W, H, spp, depth = WORKLOADS[args.workload]
     if args.spp:
         spp = args.spp
-    builder, flat, _ = host.build_config_scene(scene_name, seed=args.seed)
+    builder, flat, _ = host.build_config_scene(scene_name, seed=args.seed, bvh=args.bvh)
     if args.semantics == "intended":
         flat.semantics = abi.SEMANTICS_INTENDED
+    elif args.semantics == "book":
+        flat.semantics = abi.SEMANTICS_BOOK
     return builder, flat, scene_name, W, H, spp, depth
 
 
@@ -529,7 +534,8 @@ def run_ranks(args, world, rank):
                                    + (f" ({spp} spp in {K} slices per GPU)" if scaling == "weak" and world > 1 else ""),
                        "scene": scene_name, "width": W, "height": H, "spp": job.samples_per_pixel, "slices": job.n_slices,
                        "max_depth": depth, "parallelism": f"{partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)",
-                       "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "stack_words": info["stack_words"], "scene_bytes": info["device_bytes"]},
+                       "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "bvh": args.bvh, "stack_words": info["stack_words"],
+                       "scene_bytes": info["device_bytes"]},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
             "rays_per_sample": round(total_rays / max(1, total_samples), 4),
             "kernel_ms_per_step": [round(x, 3) for x in kernel_ms],

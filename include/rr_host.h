@@ -59,6 +59,16 @@ int rrh_constant_medium(rrh_builder* b, int boundary, float density, float r, fl
 int rrh_instance_translation(rrh_builder* b, int geometry, const float displacement[3]);
 int rrh_instance_rotation(rrh_builder* b, int geometry, int axis /*0=X,1=Y,2=Z*/, float angle_degrees);
 int rrh_bvh_node(rrh_builder* b, const int* geometries, uint32_t n, float time_0, float time_1);
+/* Which tree rrh_bvh_node, rrh_load_obj and the presets build from here on:
+ *   RRH_BVH_REFERENCE (default) the reference's: the median split of a random axis (collider.rs:173-212), by an index-range
+ *                     sort (the same tree as the reference's Theta(n^2) cloning gives for the same axis draws);
+ *   RRH_BVH_SAH       NOT the reference's, a labelled option: a surface-area-heuristic tree (16 bins), `left` the side of the
+ *                     smaller coordinates along the split axis.  Under the reference's semantics the IMAGE depends on the
+ *                     tree (collider.rs:555-561), so this is for RR_SEMANTICS_INTENDED / RR_SEMANTICS_BOOK, where a BVH
+ *                     only accelerates: it measures what the reference's tree costs next to a conventional one.          */
+#define RRH_BVH_REFERENCE 0u
+#define RRH_BVH_SAH 1u
+int rrh_set_bvh_builder(rrh_builder* b, uint32_t kind);
 /* A BVH node with caller-chosen children, axis and box (no random draw): for hand-built test trees. */
 int rrh_bvh_node_explicit(rrh_builder* b, int left, int right, uint32_t axis, int has_box, const float bmin[3],
                           const float bmax[3]);

@@ -199,6 +199,7 @@ HIP_PROTOTYPES = {
 HOST_PROTOTYPES = {
     "rrh_builder_new": (vp, [u64]),
     "rrh_builder_free": (None, [vp]),
+    "rrh_set_bvh_builder": (C.c_int, [vp, u32]),
     "rrh_last_error": (C.c_char_p, []),
     "rrh_random": (f32, [vp]),
     "rrh_randrange": (f32, [vp, f32, f32]),

@@ -33,12 +33,16 @@ AXIS_X, AXIS_Y, AXIS_Z = 0, 1, 2
 class SceneBuilder:
     """One scene under construction (SceneColliders + lights + camera + background)."""
 
-    def __init__(self, seed=1):
+    def __init__(self, seed=1, bvh="reference"):
+        """bvh: "reference" = the reference's tree (collider.rs:173-212); "sah" = a surface-area-heuristic tree, a labelled
+        option that is NOT the reference's (meant for the intended / book semantics, where a BVH only accelerates)."""
         self._l = lib()
         self._b = self._l.rrh_builder_new(seed)
         if not self._b:
             raise HostError("rrh_builder_new failed")
         self._flat = None
+        if bvh != "reference":
+            self._h(self._l.rrh_set_bvh_builder(self._b, {"sah": 1}[bvh]))
 
     def close(self):
         if self._b:
@@ -201,6 +205,7 @@ ASSETS = os.path.join(abi.REPO_DIR, "assets")
 
 def build_config_scene(name, seed=1, **kw):
     """Scenes of the benchmark configurations by short name → (builder, FlatScene, defaults).
+    bvh="sah": every BVH of the scene is a surface-area-heuristic tree instead of the reference's (a labelled option).
 
     cornell        cornell_box() verbatim (main.rs:325-368)
     spheres        random_spheres() (main.rs:50-115)
@@ -208,7 +213,7 @@ def build_config_scene(name, seed=1, **kw):
     final          final_scene() + light repair + the motion-blurred sphere (main.rs:466-541)
     mesh           synthetic height field + spheres (n_triangles, n_spheres keyword arguments)
     """
-    b = SceneBuilder(seed)
+    b = SceneBuilder(seed, bvh=kw.pop("bvh", "reference"))
     if name == "cornell":
         d = b.preset("cornell_box")
     elif name == "spheres":

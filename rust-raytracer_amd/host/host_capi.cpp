@@ -153,6 +153,13 @@ int rrh_bvh_node(rrh_builder* b, const int* gs, uint32_t n, float t0, float t1) 
         return push_geom(b, Geometry::bvh_node(items, t0, t1, 0, items.size(), b->rng));
     });
 }
+int rrh_set_bvh_builder(rrh_builder* b, uint32_t kind) {
+    return guarded([&] {
+        if (kind > 1) throw std::invalid_argument("rrh_set_bvh_builder: kind must be RRH_BVH_REFERENCE or RRH_BVH_SAH");
+        b->rng.sah_builder = kind == 1;
+        return 0;
+    });
+}
 int rrh_bvh_node_explicit(rrh_builder* b, int left, int right, uint32_t axis, int has_box, const float bmin[3],
                           const float bmax[3]) {
     return guarded([&] {

@@ -364,9 +364,120 @@ struct BvhBuild {
 };
 }  // namespace
 
+namespace {
+GeometryPtr make_bvh_node(GeometryPtr left, GeometryPtr right, uint32_t axis, float t0, float t1) {
+    auto g = std::make_shared<Geometry>();
+    g->type = GeometryType::BVHNode;
+    g->material = left->material;
+    g->axis_index = axis;
+    auto bl = left->bounding_box(t0, t1);
+    auto br = right->bounding_box(t0, t1);
+    g->has_box = true;
+    g->box = AABB::surrounding_box(*bl, *br);
+    g->children = {std::move(left), std::move(right)};
+    return g;
+}
+
+struct SahBuild {
+    struct Item {
+        GeometryPtr g;
+        AABB box;
+        float c[3];
+    };
+    std::vector<Item> items;
+    float t0, t1;
+    static constexpr int BINS = 16;
+
+    static float half_area(const float lo[3], const float hi[3]) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    GeometryPtr node(size_t start, size_t end) {
+        const size_t span = end - start;
+        if (span == 1) return make_bvh_node(items[start].g, items[start].g, 0, t0, t1);
+        if (span == 2) {
+            // the axis on which the two centres are farthest apart; the smaller coordinate on the left
+            int axis = 0;
+            for (int a = 1; a < 3; ++a)
+                if (std::fabs(items[start].c[a] - items[start + 1].c[a]) > std::fabs(items[start].c[axis] - items[start + 1].c[axis])) axis = a;
+            const bool swap = items[start].c[axis] > items[start + 1].c[axis];
+            return make_bvh_node(items[start + (swap ? 1 : 0)].g, items[start + (swap ? 0 : 1)].g, static_cast<uint32_t>(axis), t0, t1);
+        }
+        float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+        for (size_t i = start; i < end; ++i)
+            for (int a = 0; a < 3; ++a) clo[a] = std::min(clo[a], items[i].c[a]), chi[a] = std::max(chi[a], items[i].c[a]);
+        int best_axis = -1, best_bin = 0;
+        float best_cost = 3e38f;
+        for (int a = 0; a < 3; ++a) {
+            const float extent = chi[a] - clo[a];
+            if (!(extent > 0.0f)) continue;
+            size_t count[BINS] = {};
+            float lo[BINS][3], hi[BINS][3];
+            for (int b = 0; b < BINS; ++b)
+                for (int k = 0; k < 3; ++k) lo[b][k] = 3e38f, hi[b][k] = -3e38f;
+            for (size_t i = start; i < end; ++i) {
+                const int b = std::min(BINS - 1, static_cast<int>((items[i].c[a] - clo[a]) / extent * BINS));
+                count[b]++;
+                const float mn[3] = {items[i].box.minimum.x, items[i].box.minimum.y, items[i].box.minimum.z};
+                const float mx[3] = {items[i].box.maximum.x, items[i].box.maximum.y, items[i].box.maximum.z};
+                for (int k = 0; k < 3; ++k) lo[b][k] = std::min(lo[b][k], mn[k]), hi[b][k] = std::max(hi[b][k], mx[k]);
+            }
+            // cost of splitting after bin b: area(left) * n(left) + area(right) * n(right)
+            float rarea[BINS];
+            size_t rcount[BINS];
+            float rl[3] = {3e38f, 3e38f, 3e38f}, rh[3] = {-3e38f, -3e38f, -3e38f};
+            size_t rc = 0;
+            for (int b = BINS - 1; b > 0; --b) {
+                for (int k = 0; k < 3; ++k) rl[k] = std::min(rl[k], lo[b][k]), rh[k] = std::max(rh[k], hi[b][k]);
+                rc += count[b];
+                rarea[b] = rc ? half_area(rl, rh) : 0.0f;
+                rcount[b] = rc;
+            }
+            float ll[3] = {3e38f, 3e38f, 3e38f}, lh[3] = {-3e38f, -3e38f, -3e38f};
+            size_t lc = 0;
+            for (int b = 0; b + 1 < BINS; ++b) {
+                for (int k = 0; k < 3; ++k) ll[k] = std::min(ll[k], lo[b][k]), lh[k] = std::max(lh[k], hi[b][k]);
+                lc += count[b];
+                if (lc == 0 || rcount[b + 1] == 0) continue;
+                const float cost = half_area(ll, lh) * static_cast<float>(lc) + rarea[b + 1] * static_cast<float>(rcount[b + 1]);
+                if (cost < best_cost) best_cost = cost, best_axis = a, best_bin = b;
+            }
+        }
+        size_t mid;
+        if (best_axis < 0) {  // every centre in one point: halve the span as it stands
+            best_axis = 0;
+            mid = start + span / 2;
+        } else {
+            const float extent = chi[best_axis] - clo[best_axis];
+            auto first_right = std::partition(items.begin() + static_cast<std::ptrdiff_t>(start), items.begin() + static_cast<std::ptrdiff_t>(end), [&](const Item& it) {
+                return std::min(BINS - 1, static_cast<int>((it.c[best_axis] - clo[best_axis]) / extent * BINS)) <= best_bin;
+            });
+            mid = static_cast<size_t>(first_right - items.begin());
+        }
+        GeometryPtr left = node(start, mid), right = node(mid, end);
+        return make_bvh_node(std::move(left), std::move(right), static_cast<uint32_t>(best_axis), t0, t1);
+    }
+};
+}  // namespace
+
+GeometryPtr Geometry::bvh_node_sah(const std::vector<GeometryPtr>& colliders, float time_0, float time_1) {
+    if (colliders.empty()) throw std::invalid_argument("bvh_node_sah: no elements");
+    SahBuild build{{}, time_0, time_1};
+    build.items.reserve(colliders.size());
+    for (const GeometryPtr& g : colliders) {
+        auto b = g->bounding_box(time_0, time_1);
+        if (!b) throw std::invalid_argument("bvh_node_sah: element without a bounding box");
+        SahBuild::Item it{g, *b, {0.5f * (b->minimum.x + b->maximum.x), 0.5f * (b->minimum.y + b->maximum.y), 0.5f * (b->minimum.z + b->maximum.z)}};
+        build.items.push_back(std::move(it));
+    }
+    return build.node(0, build.items.size());
+}
+
 GeometryPtr Geometry::bvh_node(const std::vector<GeometryPtr>& colliders, float time_0, float time_1, size_t start,
                                size_t end, Rng& rng) {
     if (start >= end || end > colliders.size()) throw std::invalid_argument("bvh_node: empty or out-of-range span");
+    if (rng.sah_builder)  // the labelled option: not the reference's tree
+        return bvh_node_sah(std::vector<GeometryPtr>(colliders.begin() + static_cast<std::ptrdiff_t>(start), colliders.begin() + static_cast<std::ptrdiff_t>(end)), time_0, time_1);
     std::vector<GeometryPtr> items(colliders);
     std::vector<std::array<float, 3>> keys(items.size());
     for (size_t i = start; i < end; ++i) {

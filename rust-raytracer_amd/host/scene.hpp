@@ -86,6 +86,10 @@ class Rng {
             if (v < hi) return v;
         }
     }
+    // Which tree Geometry::bvh_node builds with this generator: false (default) the reference's (collider.rs:173-212: median
+    // split of a random axis: it is what draws from the generator), true a surface-area-heuristic tree (bvh_node_sah), a
+    // labelled non-parity option that draws nothing.
+    bool sah_builder = false;
     // uniform integer in [lo, hi)
     uint32_t randuint(uint32_t lo, uint32_t hi) {
         uint32_t span = hi - lo;
@@ -216,6 +220,13 @@ class Geometry {
     // Same arguments as the reference plus the Rng that supplies the split axes.
     static GeometryPtr bvh_node(const std::vector<GeometryPtr>& colliders, float time_0, float time_1,
                                 size_t start, size_t end, Rng& rng);
+    // NOT the reference's builder (a labelled option, never the default): a binary tree split by the surface-area heuristic
+    // over 16 bins of the bounding boxes' centres along the axis where that is cheapest, `left` the side of the smaller
+    // coordinates and `axis` the split axis (0 = x, 1 = y, 2 = z), so that direction[axis] >= 0 visits the nearer child first;
+    // the same node shape as the reference's tree (two children per node, a single primitive is both children of its node).
+    // What the reference's own tree costs next to a conventional one is measured with it under RR_SEMANTICS_INTENDED (under
+    // the reference's semantics the image depends on the tree, collider.rs:555-561).
+    static GeometryPtr bvh_node_sah(const std::vector<GeometryPtr>& colliders, float time_0, float time_1);
     // A BVH node with caller-chosen children, axis and box: no random draw.  For hand-built trees.
     static GeometryPtr bvh_node_explicit(GeometryPtr left, GeometryPtr right, uint32_t axis,
                                          std::optional<AABB> box);

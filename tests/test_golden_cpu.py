@@ -100,6 +100,45 @@ def test_intended_bvh_returns_what_a_linear_list_returns(built):
     assert ((ref["prim_id"] >= 0) & hit).sum() < hit.sum()  # the live semantics lose some of them (collider.rs:555-561)
 
 
+def test_sah_tree_is_a_labelled_option_that_only_accelerates(built):
+    """host.SceneBuilder(bvh="sah") builds a surface-area-heuristic tree instead of the reference's median split of a random
+    axis (collider.rs:173-212).  Under the intended semantics both trees and no tree at all return the same hits — the SAH
+    tree with far fewer box and primitive tests; under the reference's own semantics the result depends on the tree."""
+    from rust_raytracer_amd import host
+    rng = np.random.default_rng(6)
+    centers = rng.uniform(-25, 25, (400, 3))
+    radii = rng.uniform(0.3, 2.0, 400)
+    tris = rng.uniform(-25, 25, (300, 1, 3)) + rng.normal(size=(300, 3, 3)) * 1.5
+
+    def scene(bvh):
+        b = host.SceneBuilder(9, bvh=bvh or "reference")
+        m = b.lambertian(b.solid_color((0.5, 0.5, 0.5)))
+        items = [b.sphere(c, float(r), m) for c, r in zip(centers, radii)] + [b.triangle(t[0], t[1], t[2], m) for t in tris]
+        if bvh:
+            b.add(b.bvh_node(items))
+        else:
+            for g in items:
+                b.add(g)
+        b.set_camera((0, 0, -60), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+        return b, b.flatten()
+
+    (b0, plain), (b1, ref_tree), (b2, sah_tree) = scene(None), scene("reference"), scene("sah")
+    assert sah_tree.n_bvh_nodes > 0 and max(sah_tree.bvh_nodes[i].axis for i in range(sah_tree.n_bvh_nodes)) == 2  # real split axes
+    rays = np.concatenate([rng.uniform(-30, 30, (6000, 3)), rng.normal(size=(6000, 3)), rng.uniform(0, 1, (6000, 1))], axis=1).astype(np.float32)
+    lin = O.primary_hits(intended(plain), rays)
+    a, ca = O.primary_hits(intended(ref_tree), rays, counters=True)
+    s_, cs = O.primary_hits(intended(sah_tree), rays, counters=True)
+    hit = lin["prim_id"] >= 0
+    assert hit.mean() > 0.2
+    for got in (a, s_):
+        assert np.array_equal(got["prim_id"] >= 0, hit)
+        assert np.array_equal(got["t"][hit], lin["t"][hit]) and np.array_equal(got["point"][hit], lin["point"][hit])
+    assert cs["box_tests"] < 0.6 * ca["box_tests"] and cs["prim_tests"] < 0.6 * ca["prim_tests"], (cs, ca)
+    # under the reference's semantics the two trees lose different rays (collider.rs:555-561)
+    r1, r2 = O.primary_hits(ref_tree, rays), O.primary_hits(sah_tree, rays)
+    assert (r1["prim_id"] != r2["prim_id"]).mean() > 0.01
+
+
 # ------------------------------------------------------------ whole paths
 def _paths_fixture():
     import golden_paths as GP
