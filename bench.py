@@ -202,7 +202,11 @@ def parse_args(argv=None):
     ap.add_argument("--inprocess", action="store_true", help="one process, N devices through rr_multi_* instead of one rank per GPU")
     ap.add_argument("--devices", default=None, help="--inprocess: comma-separated device list (a device may repeat), default 0..N-1")
     ap.add_argument("--reduce", default="auto", choices=["auto", "rccl", "peer"], help="--inprocess: how slice groups are summed")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the ranks (gloo: --launch-check only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the ranks (gloo: --launch-check, and rehearsals with --share-gpus: images are staged through the host)")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="REHEARSAL, not a measurement of N GPUs: rank r renders on GPU r %% (GPUs visible), so that the N-rank code runs on a "
+                         "box with fewer GPUs; needs --backend gloo (RCCL refuses two ranks on one GPU); the line says n_gpus = GPUs used")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, count them with one all-reduce, print {n_gpus, n_ranks_seen} and exit: no rendering")
     return ap.parse_args(argv)
@@ -223,7 +227,12 @@ def launch_ranks(args, argv):
     import socket
     import subprocess
     have = visible_gpus(args)
-    if have < args.gpus:
+    if args.share_gpus:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --share-gpus needs --backend gloo (RCCL cannot hold one GPU twice)")
+        if have < 1:
+            raise SystemExit("bench.py: --share-gpus still needs one GPU")
+    elif have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to measure fewer GPUs than asked")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -353,6 +362,13 @@ def run_ranks(args, world, rank):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
+    rehearsal = bool(args.share_gpus and world > 1)
+    if rehearsal:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --share-gpus needs --backend gloo (RCCL cannot hold one GPU twice)")
+        local_rank = local_rank % torch.cuda.device_count()
+    elif args.backend != "nccl" and world > 1:
+        raise SystemExit("bench.py: N GPUs are measured over RCCL (--backend nccl); gloo is for --launch-check and --share-gpus rehearsals")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} wants device {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
@@ -360,8 +376,12 @@ def run_ranks(args, world, rank):
     n_ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         n_ranks_seen = dist.get_world_size()
+    gpus_used = min(world, torch.cuda.device_count()) if rehearsal else world
 
     builder, flat, scene_name, W, H, spp, depth = load_scene(args)
     K = args.slices
@@ -370,6 +390,7 @@ def run_ranks(args, world, rank):
     ctx = device.Context(local_rank)
     info = ctx.upload(flat)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev  # where the small tensors of the bookkeeping collectives live
     stream = torch.cuda.current_stream().cuda_stream
     rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
 
@@ -382,7 +403,7 @@ def run_ranks(args, world, rank):
         """W untimed and K timed steps of one job shared by the ranks -> dict of what rank 0 reports."""
         job = multi.job_params(W, H, spp, K, depth, args.seed, world, scaling, flags=args.flags)
         p = multi.rank_share(job, rank, world, partition)
-        comb = multi.Combiner(dist, world, partition, H)
+        comb = multi.Combiner(dist, world, partition, H, stage_through_host=rehearsal)
         n_sl, rows = p.slice_end - p.slice_begin, p.rows
         slice_sums = torch.empty((max(1, n_sl), rows, W, 3), dtype=torch.float32, device=dev)
         resolved = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
@@ -415,23 +436,28 @@ def run_ranks(args, world, rank):
         kernel_ms = [a.elapsed_time(b) for a, b in events]
         per_rank_ms = [float(np.mean(kernel_ms))]
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            tot = counters.clone()
+            tot = counters.to(cdev, copy=True)
             dist.all_reduce(tot)
             counts_all = tot.cpu().numpy()
-            km = torch.tensor(per_rank_ms, dtype=torch.float64, device=dev)
+            km = torch.tensor(per_rank_ms, dtype=torch.float64, device=cdev)
             allk = [torch.empty_like(km) for _ in range(world)]
             dist.all_gather(allk, km)
             per_rank_ms = [float(x.item()) for x in allk]
         else:
             counts_all = counters.cpu().numpy()
+        image = None
+        if rank == 0:  # the job's 8-bit image as rank 0 holds it after the last step: what a check of an N-GPU run compares
+            import hashlib
+            img = rgb8.cpu().numpy()
+            image = {"sha256": hashlib.sha256(img.tobytes()).hexdigest(), "mean_rgb": [round(float(x), 4) for x in img.reshape(-1, 3).mean(axis=0)]}
         spt = job.samples_per_pixel // job.n_slices
         samples_per_step = W * H * spt * job.n_slices
         assert int(counts_all[0]) == samples_per_step * args.steps, (int(counts_all[0]), samples_per_step, args.steps)
         return dict(job=job, comb=comb, elapsed=elapsed, kernel_ms=kernel_ms, per_rank_ms=per_rank_ms, counts_all=counts_all,
-                    counts_rank=counters.cpu().numpy(), value=int(counts_all[0]) / elapsed / 1e6)
+                    counts_rank=counters.cpu().numpy(), value=int(counts_all[0]) / elapsed / 1e6, image=image)
 
     m = measure(scaling, partition)
     weak = None
@@ -526,14 +552,16 @@ def run_ranks(args, world, rank):
             # the counters were collected on the kernels whose sources hash to source_sha256: anything else is a stale figure
             roofline["measured"]["stale"] = summ.get("source_sha256") != digest
         out = {
-            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen,
+            "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": gpus_used, "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {W}x{H}, {job.samples_per_pixel} spp in {job.n_slices} slices, depth {depth}"
                                    + (f" ({spp} spp in {K} slices per GPU)" if scaling == "weak" and world > 1 else ""),
                        "scene": scene_name, "width": W, "height": H, "spp": job.samples_per_pixel, "slices": job.n_slices,
-                       "max_depth": depth, "parallelism": f"{partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)",
+                       "max_depth": depth, "parallelism": f"{partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)"
+                                                           + (f"; REHEARSAL: {world} ranks share {gpus_used} GPU(s), images combined over gloo through the host"
+                                                              if rehearsal else ""),
                        "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "bvh": args.bvh, "stack_words": info["stack_words"],
                        "scene_bytes": info["device_bytes"]},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
@@ -541,6 +569,7 @@ def run_ranks(args, world, rank):
             "kernel_ms_per_step": [round(x, 3) for x in kernel_ms],
             "kernel_ms_per_rank": [round(x, 3) for x in m["per_rank_ms"]],
             "source_sha256": digest,
+            "image": m["image"],
             "roofline": roofline,
             "reference_published": {"msamples_per_s": 0.67, "source": "src/notes.txt:1-5 (Cornell box 600x600, 200 spp, depth 200, unknown CPU)"},
         }

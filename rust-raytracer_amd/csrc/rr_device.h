@@ -144,7 +144,18 @@ __device__ __forceinline__ void own_registers(DevScene& sc) {
 struct Counts {
     uint32_t rays, box_tests, sphere_tests, rect_tests, tri_tests, inst_visits, samples;
     uint32_t lane_steps, wave_steps;  // steps of the per-lane traversal machine: (lane, step) pairs that moved; steps of the wave (counted on one lane)
+#ifdef RR_SECTION_TIMERS  // timing-only build: wave clocks by section of a turn of the path kernel
+    unsigned long long sec[16], sec_last;
+#endif
 };
+#ifdef RR_SECTION_TIMERS
+__device__ unsigned long long g_sec[16];
+#define RR_SEC_MARK(cnt, k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (cnt).sec[k] += now_ - (cnt).sec_last; (cnt).sec_last = now_; } while (0)
+#define RR_SEC_ADD(cnt, k, v) do { (cnt).sec[k] += (v); } while (0)
+#else
+#define RR_SEC_MARK(cnt, k) do { } while (0)
+#define RR_SEC_ADD(cnt, k, v) do { } while (0)
+#endif
 // Counting builds of the kernels (template parameter COUNT): COUNT_REFERENCE makes every BVH visit the reference makes,
 // in its order, and counts them; COUNT_PRODUCTION counts what the production traversal (visit skipping, culling) does.
 constexpr int COUNT_OFF = 0, COUNT_REFERENCE = 1, COUNT_PRODUCTION = 2;
@@ -208,8 +219,11 @@ struct Rng {
         // a v_readlane per use).  Behind an empty asm the round keys are twenty scalar additions where a block is made.
         asm volatile("" : "+s"(ka), "+s"(kb));
 #endif
+#ifndef RR_PHILOX_ROUNDS  // (a build with fewer rounds is a timing-only build: it prices the generator)
+#define RR_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < RR_PHILOX_ROUNDS; ++r) {
             // (as one 64-bit product per pair the compiler takes v_mad_u64_u32 for both halves: measured -3.5 % on the Cornell box)
             uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
             uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
@@ -1115,6 +1129,9 @@ struct Op {
     uint32_t code, ref;
     float f0, f1, f2, f3, f4, f5;
 };
+#ifdef RR_FIXED_PROGRAM
+#include RR_FIXED_PROGRAM
+#endif
 
 // The transforms of OP_XFORM on the ray (o, d) (collider.rs:481, 499-509); returns the instance visits it counts.
 __device__ __forceinline__ uint32_t xform_op(const Op& op, uint32_t flags, f3 wo, f3 wd, f3& o, f3& d) {
@@ -1449,7 +1466,18 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         if (!(n < park_below && steps >= min_steps)) return false;
         return static_cast<uint32_t>(__popcll(RR_BALLOT(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
-#ifndef RR_PARKING_INDEXED_LOOP
+#ifdef RR_FIXED_PROGRAM  // timing-only build: the program of ONE scene as compile-time constants, what a per-scene compile would see
+#pragma unroll
+    for (uint32_t fpc = 0; fpc < RR_FIXED_N_OPS; ++fpc) {
+        Op op;
+        op.code = kFixedWords[fpc][0], op.ref = kFixedWords[fpc][1];
+        op.f0 = __builtin_bit_cast(float, kFixedWords[fpc][2]), op.f1 = __builtin_bit_cast(float, kFixedWords[fpc][3]);
+        op.f2 = __builtin_bit_cast(float, kFixedWords[fpc][4]), op.f3 = __builtin_bit_cast(float, kFixedWords[fpc][5]);
+        op.f4 = __builtin_bit_cast(float, kFixedWords[fpc][6]), op.f5 = __builtin_bit_cast(float, kFixedWords[fpc][7]);
+        const uint32_t this_pc = fpc;
+        const uint32_t code = op.code & 0xFFu;
+        (void)prog, (void)next, (void)pc;
+#elif !defined(RR_PARKING_INDEXED_LOOP)
     // A counted loop over a moving pointer, as in traverse.  (Measured slower here while the kernel was short of scalar registers,
     // -1.5 % final_scene and -4.6 % Suzanne; once own_registers and the Philox round keys had given scalar registers back: +1.7 % and +5.6 %.)
     const uint32_t n_ops = uni(sc.n_ops);
@@ -1475,7 +1503,12 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             // A subtree of BVH nodes over spheres, rects, triangles and cuboids.  The root's box and class travel in the op:
             // its test (collider.rs:537-545) is made here for all lanes at once, with scalar operands, and only the lanes
             // that pass descend, on the moves that know nothing but BVH frames and those four kinds of leaves.
+            RR_SEC_MARK(cnt, 1);
             const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
+            // (Tried: lanes parked at ANOTHER simple subtree take the steps of this visit as well, on their own descent — their
+            // machine state is complete in their slot and their stack is their own.  Bit-identical, and on final_scene, the one
+            // benchmark scene with two subtrees, the later subtree's visits fell from 3.85 to 2.93 steps per turn: +0.3 %; the
+            // bookkeeping cost scenes with one subtree 1.6-2.9 %.  Few lanes are parked at any time; not kept.)
             Trav m;
             m.begin(NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
             if (rejoin) park_load(pa, slot, s, m, sc.lean == 0u, true);
@@ -1501,6 +1534,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             asm volatile("" ::"s"(left), "s"(right));
             if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
             const bool in = enter || rejoin;
+            RR_SEC_MARK(cnt, 4);
+            RR_SEC_ADD(cnt, this_pc < 4u ? 12 : 13, static_cast<unsigned long long>(__popcll(RR_BALLOT(in))));
             // (a visit of a subtree over triangles counts from a head start: at least TRIANGLE_MIN_STEPS instead of min_steps.
             // Most rays are done with a mesh in two or three moves, so that the steps a visit is made to take run with few lanes:
             // Suzanne +2.9 %, the 1.1 M-primitive mesh +3 %)
@@ -1524,8 +1559,12 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 if (going) trav_pop_simple(sc, m, stk, stride);
                 if (COUNT) cnt.lane_steps += going ? 1u : 0u, cnt.wave_steps += (threadIdx.x & 63u) == 0 ? 1u : 0u;
                 steps += 1;
+                RR_SEC_ADD(cnt, this_pc < 4u ? 8 : 9, 1ull);
+                RR_SEC_ADD(cnt, this_pc < 4u ? 14 : 15, static_cast<unsigned long long>(n));
             }
+            RR_SEC_MARK(cnt, this_pc < 4u ? 2 : 3);
             park_settle(pa, s, m, slot, in, this_pc, act, sc.lean == 0u, true);
+            RR_SEC_MARK(cnt, 4);
         } else if (code == OP_SUBTREE) {
 #ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce
             continue;

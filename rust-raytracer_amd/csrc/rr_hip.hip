@@ -1436,8 +1436,11 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
                                             "SUBTREE", "MED_BEGIN", "MED_MID", "MED_END", "CUBOID", "SUBTREE_SIMPLE", "MED_SPHERE", "XFORM"};
         for (size_t i = 0; i < pb.ops.size(); ++i) {
             const Op& o = pb.ops[i];
-            std::fprintf(stderr, "op %3zu %-14s flags %02x ref %08x  %g %g %g %g %g %g\n", i, names[std::min<uint32_t>(o.code & 0xFFu, 18u)], o.code >> 8, o.ref,
-                         o.f0, o.f1, o.f2, o.f3, o.f4, o.f5);
+            uint32_t w[8];
+            std::memcpy(w, &o, sizeof(w));
+            std::fprintf(stderr, "op %3zu %-14s flags %02x ref %08x  %g %g %g %g %g %g  words %08x %08x %08x %08x %08x %08x %08x %08x\n", i,
+                         names[std::min<uint32_t>(o.code & 0xFFu, 18u)], o.code >> 8, o.ref, o.f0, o.f1, o.f2, o.f3, o.f4, o.f5, w[0], w[1], w[2], w[3], w[4], w[5],
+                         w[6], w[7]);
         }
     }
     static_assert(sizeof(Op) == 32, "one op is two 16-byte words");
@@ -2148,3 +2151,13 @@ int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, ui
 }
 
 }  // extern "C"
+
+#ifdef RR_SECTION_TIMERS  // timing-only build: reads (and clears) the wave clocks the path kernel has added up by section
+extern "C" int rr_debug_section_cycles(unsigned long long* out16) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rrdev::g_sec), 16 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rrdev::g_sec), zero, sizeof(zero)) != hipSuccess) return 3;
+    return 0;
+}
+#endif

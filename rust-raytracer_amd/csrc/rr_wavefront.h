@@ -228,7 +228,11 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
     if (PARK) pa.init(lds_stack + a.stack_words * WF_BLOCK);
     // The loop is uniform per wave (its only exit is a wave vote); lanes differ through flags.  That keeps the
     // scene-program interpreter inside traverse() in uniform control flow, on the scalar unit.
+#ifdef RR_SECTION_TIMERS
+    cnt.sec_last = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        RR_SEC_MARK(cnt, 7);
         const uint64_t idle = RR_BALLOT(!path_active);
         if (!exhausted && idle != 0) {
             if (chunk_pos == chunk_end) {
@@ -261,9 +265,12 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             continue;
         }
         // ---- one ray_color call (render.rs:15-41) for every lane that has a path
+        RR_SEC_MARK(cnt, 0);
         const bool run = path_active && depth_left != 0;
         const bool was_parked = PARK && park != NONE;
         if (run && !was_parked) cnt.rays++;
+        RR_SEC_ADD(cnt, 10, 1ull);
+        RR_SEC_ADD(cnt, 11, static_cast<unsigned long long>(__popcll(RR_BALLOT(run))));
         Rng g;
         g.start(a.seed, pixel, sample, bounce);
         float t;
@@ -280,6 +287,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
         } else {
             traverse<COUNT, VEC>(sc, ro, rd, time, 0.001f, kF32Max, run, g, stk, stride, t, ref, cnt);
         }
+        RR_SEC_MARK(cnt, 1);
         f3 terminal = mk3(0.f, 0.f, 0.f);
         bool go_on = false;
         if (run && !parked) {
@@ -299,12 +307,18 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
                 terminal = b.value;
             }
         }
+        RR_SEC_MARK(cnt, 5);
         if (path_active && !go_on && !parked) {
             const f3 c = thr * terminal;  // the sample's value (render.rs:99 adds it to the pixel)
             values[p] = make_float4(c.x, c.y, c.z, 0.f);
             path_active = false;
         }
+        RR_SEC_MARK(cnt, 6);
     }
+#ifdef RR_SECTION_TIMERS
+    if ((threadIdx.x & 63u) == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_sec[i], cnt.sec[i]);
+#endif
     flush_counts(cnt, counters);
 }
 

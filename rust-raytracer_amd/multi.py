@@ -78,7 +78,10 @@ class Combiner:
     Creating one is collective (every rank of the world calls it with the same arguments): it sets up one process
     group per band (for the reduce over slice groups) and one of the bands' first ranks (for the gather)."""
 
-    def __init__(self, dist, world, partition, height):
+    def __init__(self, dist, world, partition, height, stage_through_host=False):
+        # stage_through_host: the images are copied to host memory for the collectives and the result back to the device of
+        # rank 0's tensors (for a process group that cannot take device tensors, e.g. gloo in a rehearsal on shared GPUs)
+        self.stage = bool(stage_through_host)
         self.dist = dist if (dist is not None and world > 1) else None
         self.world = world
         self.bands, self.groups = grid(world, partition)
@@ -105,12 +108,18 @@ class Combiner:
         import torch
         dist = self.dist
         tensors = list(tensors)
+        home = tensors[0].device if tensors else None
+        if self.stage:
+            tensors = [t.cpu() for t in tensors]
+            back = lambda ts: [t.to(home) for t in ts]  # noqa: E731
+        else:
+            back = lambda ts: ts  # noqa: E731
         if self.groups > 1:  # the mutex sum of render.rs:141-150 over the slice groups of this band
             root = self.band * self.groups
             for t in tensors:
                 dist.reduce(t, dst=root, group=self.band_group)
         if self.bands == 1:
-            return tensors if self.rank == 0 else None
+            return back(tensors) if self.rank == 0 else None
         if self.group != 0:
             return None
         out = []
@@ -124,7 +133,7 @@ class Combiner:
             if self.rank == 0:
                 rows = [_cut(self.height, self.bands, b) for b in range(self.bands)]
                 out.append(torch.cat([parts[b][:r1 - r0] for b, (r0, r1) in enumerate(rows)], dim=0))
-        return out if self.rank == 0 else None
+        return back(out) if self.rank == 0 else None
 
 
 def reduce_images(dist, tensors, dst=0):

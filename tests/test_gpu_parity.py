@@ -924,6 +924,41 @@ def test_bench_drives_the_number_of_gpus_it_is_asked_for():
     assert out["value"] > 100.0 and "slices" in out["config"]["parallelism"]
 
 
+def test_bench_rank_path_rehearsed_with_ranks_sharing_the_gpu():
+    """The one-rank-per-GPU route of bench.py (launcher -> N ranks -> each renders its share -> reduce / gather -> rank 0 casts)
+    run end to end with 2 and 4 ranks that share this box's one GPU: --share-gpus over gloo, the images staged through the
+    host (RCCL cannot hold one GPU twice, so its transport is the one thing this does not run).  Bands of rows give the
+    one-rank image bit for bit; slice groups give it up to the association of the f32 sum (8-bit values within 1)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(abi.REPO_DIR, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--workload", "cornell", "--spp", "64", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-count"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, bench] + extra + common, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run([])
+    assert one["n_gpus"] == 1 and one["n_ranks_seen"] == 1
+    rows = run(["--gpus", "2", "--share-gpus", "--backend", "gloo", "--partition", "rows", "--no-weak"])
+    assert rows["n_ranks_seen"] == 2 and rows["n_gpus"] == 1 and "REHEARSAL" in rows["config"]["parallelism"]
+    assert rows["image"]["sha256"] == one["image"]["sha256"]
+    assert len(rows["kernel_ms_per_rank"]) == 2
+    sl = run(["--gpus", "2", "--share-gpus", "--backend", "gloo"])  # the defaults of an N-GPU run: strong over slices, then the weak job
+    assert sl["n_ranks_seen"] == 2 and sl["scaling"] == "strong" and "slices x2" in sl["config"]["parallelism"]
+    assert sl["config"]["spp"] == 64 and sl["weak"]["value"] > 0 and "128 spp in 16 slices" in sl["weak"]["workload"]
+    assert np.allclose(sl["image"]["mean_rgb"], one["image"]["mean_rgb"], atol=0.01)
+    both = run(["--gpus", "4", "--share-gpus", "--backend", "gloo", "--partition", "both", "--no-weak"])  # 2 bands x 2 slice groups: sub-groups
+    assert both["n_ranks_seen"] == 4 and "2 bands x 2 slice groups" in both["config"]["parallelism"]
+    assert np.allclose(both["image"]["mean_rgb"], one["image"]["mean_rgb"], atol=0.01)
+    # without --share-gpus the same command is refused (one GPU visible), and gloo is not a backend N GPUs are measured over
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo"] + common, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_full_size_cornell_configuration(gpu_ctx):
     """The headline benchmark configuration at full size (Cornell box, 600x600, 1000 spp, depth 200): every sample is traced,
     nothing is NaN, the image energy equals a low-spp oracle render's within Monte-Carlo error."""
