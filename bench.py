@@ -207,6 +207,8 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpus", action="store_true",
                     help="REHEARSAL, not a measurement of N GPUs: rank r renders on GPU r %% (GPUs visible), so that the N-rank code runs on a "
                          "box with fewer GPUs; needs --backend gloo (RCCL refuses two ranks on one GPU); the line says n_gpus = GPUs used")
+    ap.add_argument("--specialize", default="auto", choices=["auto", "always", "off"],
+                    help="rr_scene_specialize after the upload (outside the timed region, like the upload): auto = only programs without BVH subtrees")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, count them with one all-reduce, print {n_gpus, n_ranks_seen} and exit: no rendering")
     return ap.parse_args(argv)
@@ -324,6 +326,8 @@ def run_inprocess(args):
     split = {"slices": abi.SPLIT_SLICES, "rows": abi.SPLIT_ROWS, "both": abi.SPLIT_BOTH}[partition]
     mc = device.MultiContext(devices, reduce=args.reduce)
     mc.upload(flat)
+    if args.specialize != "off":
+        mc.specialize(args.specialize)
     for _ in range(args.warmup):
         r = mc.render(job, split)
     t0 = time.perf_counter()
@@ -389,6 +393,8 @@ def run_ranks(args, world, rank):
     partition = args.partition or default_partition(world, K)
     ctx = device.Context(local_rank)
     info = ctx.upload(flat)
+    if args.specialize != "off":
+        info = ctx.specialize(args.specialize)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearsal else dev  # where the small tensors of the bookkeeping collectives live
     stream = torch.cuda.current_stream().cuda_stream
@@ -478,7 +484,8 @@ def run_ranks(args, world, rank):
         elif pipeline:
             kernel_name = "wavefront pipeline: k_wf_init + k_wf_traverse + k_wf_shade (camera rays) + k_wf_finish + k_wf_accumulate"
         else:
-            kernel_name = "k_wf_paths (persistent kernel at path granularity) + k_wf_accumulate"
+            kernel_name = ("k_wf_paths (persistent kernel at path granularity" + (", compiled for this scene's program by rr_scene_specialize" if info["specialized"] else "")
+                           + ") + k_wf_accumulate")
 
         # What the kernels did per ray, from instrumented passes outside the timed region on a reduced image (per-ray
         # averages do not depend on the image size): `production` counts the tests of the traversal the timed kernels run
@@ -563,7 +570,8 @@ def run_ranks(args, world, rank):
                                                            + (f"; REHEARSAL: {world} ranks share {gpus_used} GPU(s), images combined over gloo through the host"
                                                               if rehearsal else ""),
                        "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "bvh": args.bvh, "stack_words": info["stack_words"],
-                       "scene_bytes": info["device_bytes"]},
+                       "scene_bytes": info["device_bytes"], "specialized": info["specialized"],
+                       "specialize_ms": round(info["specialize_ms"], 1)},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),
             "rays_per_sample": round(total_rays / max(1, total_samples), 4),
             "kernel_ms_per_step": [round(x, 3) for x in kernel_ms],

@@ -334,6 +334,8 @@ typedef struct rr_scene_info {
     uint64_t workspace_bytes; /* device memory the context's render calls have allocated so far (grow-only workspace and work
                                 counter of rr_render_device / rr_render); stays 0 on a context that only ever rendered through
                                 rr_render_device_noalloc                                                                    */
+    uint32_t specialized;    /* 1: rr_scene_specialize has installed a kernel compiled for this scene's program            */
+    float specialize_ms;     /* what that took (compile, or the look-up of an earlier compile of the same program, and load) */
 } rr_scene_info;
 
 typedef struct rr_context rr_context;
@@ -357,6 +359,34 @@ int rr_context_destroy(rr_context* ctx);
  * of render_multi (render.rs:128).  A later call replaces the scene.        */
 int rr_scene_upload(rr_context* ctx, const rr_flat_scene* scene);
 int rr_scene_info_get(rr_context* ctx, rr_scene_info* out);
+
+/* Compile the path kernel for THIS scene's program.  No counterpart in the reference (its scene is Rust data walked by
+ * compiled match arms, collider.rs:751-772); here the top level of the scene is a short program of ops (one per sphere, rect,
+ * cuboid, transform, medium or BVH subtree at the root) that the kernels of the library interpret: fetched and dispatched by
+ * the scalar unit for every ray.  This call hands the same device source, with the uploaded scene's ops as compile-time
+ * constants and the op loop unrolled, to the runtime compiler (libhiprtc.so, opened at the first call; same options as the
+ * library's own build, so the arithmetic contract -- one IEEE f32 operation per source operation -- is the same) and installs the
+ * result in place of the interpreter for rr_render_device / _noalloc / rr_render calls without counting flags.  Images are bit
+ * for bit those of the interpreter.  Measured: Cornell box (10 ops, no BVH) +16 % with the runtime compiler a PyTorch process
+ * brings along (ROCm 7.0's) and +24 % with the compiler of the library's own build (ROCm 7.2's, which is what libhiprtc.so is in
+ * a process without PyTorch); scenes with BVH subtrees, whose walk dominates, lose 1-13 % (final_scene, Suzanne, random
+ * spheres); about 1-3 s of compile per new program, remembered per process.
+ *   RR_SPECIALIZE_AUTO    only where it is expected to pay: programs without BVH subtrees (returns RR_OK and leaves
+ *                         rr_scene_info.specialized at 0 otherwise)
+ *   RR_SPECIALIZE_ALWAYS  whatever the program
+ *   RR_SPECIALIZE_OFF     back to the interpreter
+ * A later rr_scene_upload drops it.  Fails with RR_E_NO_DEVICE when libhiprtc.so cannot be opened and RR_E_HIP with the
+ * compiler's log when the compile fails; the interpreter stays in place then.  Not for callers that cannot allocate or wait:
+ * it compiles and loads a code object. */
+#define RR_SPECIALIZE_AUTO   0u
+#define RR_SPECIALIZE_ALWAYS 1u
+#define RR_SPECIALIZE_OFF    2u
+int rr_scene_specialize(rr_context* ctx, uint32_t mode);
+/* The compiler options of rr_scene_specialize, space separated (a test holds them against the library's own build), and a
+ * check that needs no GPU: a two-op program is put through the runtime compiler (ms: what that took).  No counterpart in the
+ * reference. */
+const char* rr_specialize_options(void);
+int rr_specialize_selftest(float* ms);
 
 /* Closest-hit records for caller-supplied rays, exactly as
  * SceneColliders::intersect(r, t_min, t_max) returns them (collider.rs:751).
@@ -459,6 +489,7 @@ typedef struct rr_multi rr_multi;
 int rr_multi_create(int n_devices, const int* devices, rr_multi** out);
 int rr_multi_destroy(rr_multi* m);
 int rr_multi_scene_upload(rr_multi* m, const rr_flat_scene* scene);
+int rr_multi_scene_specialize(rr_multi* m, uint32_t mode); /* rr_scene_specialize on every device (the program is compiled once) */
 int rr_multi_render(rr_multi* m, const rr_render_params* job, uint32_t split, uint8_t* out_rgb8,
                     float* out_resolved, float* out_linear, rr_counters* out_counters);
 

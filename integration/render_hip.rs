@@ -272,6 +272,7 @@ pub fn render_hip_on(devices: &[i32], scene: SceneColliders, lights: Geometry, c
         let mut multi = null_mut();
         let mut rc = unsafe { rr_multi_create(devices.len() as i32, devices.as_ptr(), &mut multi) };
         if rc == RR_OK { rc = unsafe { rr_multi_scene_upload(multi, &flat) }; }
+        if rc == RR_OK { let _ = unsafe { rr_multi_scene_specialize(multi, RR_SPECIALIZE_AUTO) }; } // (as below)
         if rc == RR_OK { rc = unsafe { rr_multi_render(multi, &p, RR_SPLIT_ROWS, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut()) }; }
         if rc == RR_OK {
             done = true;
@@ -285,6 +286,9 @@ pub fn render_hip_on(devices: &[i32], scene: SceneColliders, lights: Geometry, c
         let mut ctx = null_mut();
         check(unsafe { rr_context_create(devices[0], &mut ctx) });
         check(unsafe { rr_scene_upload(ctx, &flat) });
+        // A kernel compiled for this scene's top-level program where that pays (about a second with the runtime compiler; the
+        // image is the same bits).  Optional: without libhiprtc.so the interpreter renders.
+        let _ = unsafe { rr_scene_specialize(ctx, RR_SPECIALIZE_AUTO) };
         check(unsafe { rr_render(ctx, &p, rgb.as_mut_ptr(), null_mut(), null_mut(), null_mut(), null_mut()) });
         unsafe { rr_context_destroy(ctx) };
     }

@@ -12,6 +12,12 @@ fn main() {
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
     let ok = Command::new(&hipcc)
         .args(["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"])
+        // rr_device.h includes "rr_hip.h"; the library also embeds the text of its device headers (for rr_scene_specialize),
+        // which the assembler looks for along the same paths
+        .arg("-I")
+        .arg(root.join("rust-raytracer_amd/csrc"))
+        .arg("-I")
+        .arg(root.join("include"))
         .arg(&src)
         .arg("-o")
         .arg(&so)

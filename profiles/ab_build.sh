@@ -6,6 +6,7 @@ set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p "$ROOT/ab"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wall "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -Wall \
+    -I "$ROOT/rust-raytracer_amd/csrc" -I "$ROOT/include" "$@" \
     -o "$ROOT/ab/librr_hip_$NAME.so" "$ROOT/rust-raytracer_amd/csrc/rr_hip.hip"
 echo "built ab/librr_hip_$NAME.so"

@@ -13,7 +13,7 @@ import rust_raytracer_amd  # noqa: E402,F401
 from rust_raytracer_amd import build  # noqa: E402
 
 src = os.path.join(build.CSRC, "rr_hip.hip")
-r = subprocess.run(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/rr_resources.so", src],
+r = subprocess.run(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-I", build.CSRC, "-I", build.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/rr_resources.so", src],
                    capture_output=True, text=True)
 want = sys.argv[1:] or ["k_wf_paths", "k_wf_traverse", "k_wf_finish", "k_render", "k_wf_shade"]
 for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:

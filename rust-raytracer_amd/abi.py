@@ -31,6 +31,7 @@ NOALLOC_MAX_PATHS = 4194304
 EVAL_COLOR, EVAL_TURB, EVAL_NOISE = 0, 1, 2
 SPLIT_SLICES, SPLIT_ROWS, SPLIT_BOTH = 0, 1, 2
 REDUCE_AUTO, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
+SPECIALIZE_AUTO, SPECIALIZE_ALWAYS, SPECIALIZE_OFF = 0, 1, 2
 SEMANTICS_REFERENCE, SEMANTICS_INTENDED, SEMANTICS_BOOK_ESTIMATOR, SEMANTICS_BOOK = 0, 1, 2, 3
 
 
@@ -156,7 +157,7 @@ class Hit(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("stack_words", u32), ("max_inst_depth", u32), ("device_bytes", u64), ("n_prims", u32),
                 ("wavefront", u32), ("bvh_nodes_by_class", u32 * 4), ("subtree_ops", u32 * 2),
-                ("wide_nodes", u32), ("workspace_bytes", u64)]
+                ("wide_nodes", u32), ("workspace_bytes", u64), ("specialized", u32), ("specialize_ms", f32)]
 
 
 class PresetOptions(C.Structure):
@@ -180,6 +181,9 @@ HIP_PROTOTYPES = {
     "rr_context_destroy": (C.c_int, [vp]),
     "rr_scene_upload": (C.c_int, [vp, P(FlatScene)]),
     "rr_scene_info_get": (C.c_int, [vp, P(SceneInfo)]),
+    "rr_scene_specialize": (C.c_int, [vp, u32]),
+    "rr_specialize_options": (C.c_char_p, []),
+    "rr_specialize_selftest": (C.c_int, [f3]),
     "rr_primary_hits": (C.c_int, [vp, u32, f3, f32, f32, u64, P(Hit)]),
     "rr_eval_textures": (C.c_int, [vp, u32, P(u32), f3, u32, f3]),
     "rr_render_device": (C.c_int, [vp, P(RenderParams), vp, vp, vp, vp, vp]),
@@ -191,6 +195,7 @@ HIP_PROTOTYPES = {
     "rr_multi_destroy": (C.c_int, [vp]),
     "rr_multi_scene_upload": (C.c_int, [vp, P(FlatScene)]),
     "rr_multi_render": (C.c_int, [vp, P(RenderParams), u32, P(u8), f3, f3, P(Counters)]),
+    "rr_multi_scene_specialize": (C.c_int, [vp, u32]),
     "rr_multi_set_reduce": (C.c_int, [vp, u32]),
     "rr_multi_reduce_used": (C.c_int, [vp, P(u32)]),
     "rr_last_error": (C.c_char_p, []),

@@ -59,7 +59,9 @@ def build_hip(force=False):
     deps = src + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + _headers()
     if force or _stale(abi.HIP_LIB, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIPCC_FLAGS + ["-o", abi.HIP_LIB] + src)
+        # (-I: rr_device.h includes "rr_hip.h", and the library embeds the text of its device headers, which the assembler
+        # looks for along the same paths; kept out of HIPCC_FLAGS so that source_digest() does not depend on where the tree lies)
+        _run([hipcc] + HIPCC_FLAGS + ["-I", CSRC, "-I", INCLUDE, "-o", abi.HIP_LIB] + src)
     return abi.HIP_LIB
 
 

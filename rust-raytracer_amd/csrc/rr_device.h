@@ -8,10 +8,12 @@
 // in the last bits.
 #pragma once
 
+#ifndef __HIPCC_RTC__  // (the runtime compiler brings its own runtime header and fixed-width integer types)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
-#include "../../include/rr_hip.h"
+#include "rr_hip.h"  // include/rr_hip.h (the build names the directory)
 
 namespace rrdev {
 
@@ -156,6 +158,33 @@ __device__ unsigned long long g_sec[16];
 #define RR_SEC_MARK(cnt, k) do { } while (0)
 #define RR_SEC_ADD(cnt, k, v) do { } while (0)
 #endif
+// Minimum waves per SIMD the register allocator must leave room for in the render kernels.
+#ifndef RR_RENDER_WAVES_PER_SIMD
+#define RR_RENDER_WAVES_PER_SIMD 4
+#endif
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = __shfl_down(static_cast<unsigned>(v), off, 64);
+        unsigned hi = __shfl_down(static_cast<unsigned>(v >> 32), off, 64);
+        v += (static_cast<unsigned long long>(hi) << 32) | lo;
+    }
+    return v;
+}
+
+// A wave's counts added to the ten 64-bit counters of rr_counters (one atomic per counter and wave).
+__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* counters) {
+    if (!counters) return;
+    unsigned long long v[10] = {c.samples, c.rays, c.box_tests, (unsigned long long)c.sphere_tests + c.rect_tests + c.tri_tests, c.inst_visits, c.sphere_tests, c.rect_tests, c.tri_tests,
+                                c.lane_steps, c.wave_steps};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        unsigned long long s = wave_sum(v[i]);
+        if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&counters[i], s);
+    }
+}
+
 // Counting builds of the kernels (template parameter COUNT): COUNT_REFERENCE makes every BVH visit the reference makes,
 // in its order, and counts them; COUNT_PRODUCTION counts what the production traversal (visit skipping, culling) does.
 constexpr int COUNT_OFF = 0, COUNT_REFERENCE = 1, COUNT_PRODUCTION = 2;
@@ -1129,6 +1158,10 @@ struct Op {
     uint32_t code, ref;
     float f0, f1, f2, f3, f4, f5;
 };
+// RR_FIXED_PROGRAM names a file with the ops of ONE scene's program as constants (RR_FIXED_N_OPS, kFixedWords[n][8]: the eight
+// words of every op): traverse and traverse_parking then run an unrolled copy of the interpreter's loop in which every op's
+// code and operands are known to the compiler.  That is the build rr_scene_specialize makes at run time for an uploaded
+// scene; the library's own kernels are built without it.
 #ifdef RR_FIXED_PROGRAM
 #include RR_FIXED_PROGRAM
 #endif
@@ -1222,6 +1255,17 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
     asm volatile("" ::"s"(next.code));  // the first op has arrived before the loop: inside it only the fetch of the op after the current one is in flight
     // A counted loop over a moving pointer: the scalar unit is shared by the sixteen waves of a CU, and every scalar instruction
     // of an op's fetch and dispatch (index arithmetic, a test for OP_END with its exit bookkeeping) is paid sixteen times.
+#ifdef RR_FIXED_PROGRAM  // (a per-scene build: see struct Op)
+#pragma unroll
+    for (uint32_t fpc = 0; fpc < RR_FIXED_N_OPS; ++fpc) {
+        Op op;
+        op.code = kFixedWords[fpc][0], op.ref = kFixedWords[fpc][1];
+        op.f0 = __builtin_bit_cast(float, kFixedWords[fpc][2]), op.f1 = __builtin_bit_cast(float, kFixedWords[fpc][3]);
+        op.f2 = __builtin_bit_cast(float, kFixedWords[fpc][4]), op.f3 = __builtin_bit_cast(float, kFixedWords[fpc][5]);
+        op.f4 = __builtin_bit_cast(float, kFixedWords[fpc][6]), op.f5 = __builtin_bit_cast(float, kFixedWords[fpc][7]);
+        const uint32_t code = op.code & 0xFFu;
+        (void)prog, (void)next;
+#else
     const uint32_t n_ops = uni(sc.n_ops);
     for (uint32_t pc = 0; pc != n_ops; ++pc) {
         // the op after this one is fetched while this one executes (the program ends in two OP_ENDs)
@@ -1229,6 +1273,7 @@ __device__ __forceinline__ void traverse(const DevScene& sc, f3 wo, f3 wd, float
         ++prog;
         next = *prog;
         const uint32_t code = uni(op.code) & 0xFFu;
+#endif
         if (code >= OP_RECT_XY && code <= OP_RECT_YZ) {
             if (COUNT && live) cnt.rect_tests++;
             float t;
@@ -1466,7 +1511,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
         if (!(n < park_below && steps >= min_steps)) return false;
         return static_cast<uint32_t>(__popcll(RR_BALLOT(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
-#ifdef RR_FIXED_PROGRAM  // timing-only build: the program of ONE scene as compile-time constants, what a per-scene compile would see
+#ifdef RR_FIXED_PROGRAM  // (a per-scene build: see struct Op)
 #pragma unroll
     for (uint32_t fpc = 0; fpc < RR_FIXED_N_OPS; ++fpc) {
         Op op;

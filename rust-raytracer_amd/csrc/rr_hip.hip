@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -23,11 +25,22 @@
 
 using namespace rrdev;
 
-// ================================================================= kernels
-// Minimum waves per SIMD the register allocator must leave room for in the render kernel.
-#ifndef RR_RENDER_WAVES_PER_SIMD
-#define RR_RENDER_WAVES_PER_SIMD 4
+// The device sources as text inside the library, for rr_scene_specialize: it hands them, unchanged, to the runtime compiler
+// together with the ops of one scene.  (The assembler reads the files where the build's -I options point.)
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".pushsection .rodata\n"
+        ".global rr_src_device_h\n.hidden rr_src_device_h\nrr_src_device_h:\n.incbin \"rr_device.h\"\n.byte 0\n"
+        ".global rr_src_wavefront_h\n.hidden rr_src_wavefront_h\nrr_src_wavefront_h:\n.incbin \"rr_wavefront.h\"\n.byte 0\n"
+        ".global rr_src_api_h\n.hidden rr_src_api_h\nrr_src_api_h:\n.incbin \"rr_hip.h\"\n.byte 0\n"
+        ".popsection\n");
 #endif
+extern "C" {
+extern const char rr_src_device_h[] __attribute__((visibility("hidden")));
+extern const char rr_src_wavefront_h[] __attribute__((visibility("hidden")));
+extern const char rr_src_api_h[] __attribute__((visibility("hidden")));
+}
+
+// ================================================================= kernels
 struct RenderArgs {
     uint32_t width, height; // of the whole image
     uint32_t row0, rows;    // the band of image rows [row0, row0 + rows) this launch renders
@@ -42,27 +55,6 @@ struct RenderArgs {
     uint64_t seed;
     unsigned long long* next_item;  // the first work item no wave has claimed yet (zero at launch)
 };
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned lo = __shfl_down(static_cast<unsigned>(v), off, 64);
-        unsigned hi = __shfl_down(static_cast<unsigned>(v >> 32), off, 64);
-        v += (static_cast<unsigned long long>(hi) << 32) | lo;
-    }
-    return v;
-}
-
-__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* counters) {
-    if (!counters) return;
-    unsigned long long v[10] = {c.samples, c.rays, c.box_tests, (unsigned long long)c.sphere_tests + c.rect_tests + c.tri_tests, c.inst_visits, c.sphere_tests, c.rect_tests, c.tri_tests,
-                                c.lane_steps, c.wave_steps};
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        unsigned long long s = wave_sum(v[i]);
-        if ((threadIdx.x & 63u) == 0 && s) atomicAdd(&counters[i], s);
-    }
-}
 
 #ifndef RR_RENDER_CHUNK
 #define RR_RENDER_CHUNK 64u  // work items a wave claims at a time
@@ -351,6 +343,12 @@ struct rr_context {
     hipStream_t wf_aux = nullptr;                 // k_wf_finish and the accumulation of a batch run here, beside the next batch
     hipEvent_t wf_ev_main[2] = {nullptr, nullptr};  // per workspace: the batch's bounce loop is enqueued
     hipEvent_t wf_ev_aux[2] = {nullptr, nullptr};   // per workspace: the batch is accumulated, the workspace is free
+    // rr_scene_specialize: the uploaded program's ops (eight words each, without the closing OP_ENDs), and the path kernel
+    // compiled for them: its module, its function and the template arguments it was instantiated with
+    std::vector<uint32_t> prog_words;
+    hipModule_t jit_mod = nullptr;
+    hipFunction_t jit_fn = nullptr;
+    std::string jit_targs;
 };
 
 namespace {
@@ -808,9 +806,10 @@ int set_device(rr_context* ctx) {
     return RR_OK;
 }
 
-int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid) {
+int launch_dims(rr_context* ctx, size_t lds_bytes, const void* kernel, int* grid, hipFunction_t module_fn = nullptr) {
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
+    if (module_fn) HIP_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, module_fn, 256, lds_bytes));
+    else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes));
     if (per_cu < 1) {
         const size_t stacks = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u;
         return fail(RR_E_LIMIT, "a workgroup of this kernel needs " + std::to_string(lds_bytes) + " bytes of LDS (" + std::to_string(stacks) +
@@ -1010,6 +1009,41 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     return RR_OK;
 }
 
+// Which build of k_wf_paths renders the context's scene, and the template arguments it is an instance of, as text: what
+// rr_scene_specialize instantiates in its per-scene compile.
+using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
+struct PathsChoice {
+    PathsKernel fn;
+    const char* targs;
+};
+constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
+#define RR_PK(...) PathsChoice{k_wf_paths<__VA_ARGS__>, #__VA_ARGS__}
+PathsChoice choose_paths_kernel(const rr_context* ctx, int count) {
+    // (a scene without BVH nodes has no visits to skip: its two counting modes are one kernel)
+    // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and for lean scenes
+    // (rr_context::lean_scene) the builds at 5 waves per SIMD instead of 4 that leave out what such scenes do not need (see k_wf_paths).
+    const bool ref_sem = ctx->sc.intended == 0u && ctx->sc.book == 0u, w5 = ctx->lean_scene && !ctx->has_triangles;
+    if (ctx->has_subtrees) {
+        if (count == COUNT_PRODUCTION) return RR_PK(COUNT_PRODUCTION, true, true);
+        if (count == COUNT_REFERENCE) return RR_PK(COUNT_REFERENCE, true, true);
+        if (!ref_sem) return ctx->has_general_subtrees ? RR_PK(COUNT_OFF, true, true) : RR_PK(COUNT_OFF, true, true, false);
+        if (ctx->has_general_subtrees) return w5 ? RR_PK(COUNT_OFF, true, true, true, true, W5, true) : RR_PK(COUNT_OFF, true, true, true, true);
+        // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
+        // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
+        return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false);
+    }
+    if (ctx->prog_vector_ops) {
+        // (without subtrees REF_SEM only concerns shading: the builds that know the book estimator is off do not carry its code)
+        if (count) return RR_PK(COUNT_REFERENCE, true);
+        if (ref_sem) return w5 ? RR_PK(COUNT_OFF, true, false, true, true, W5, true) : RR_PK(COUNT_OFF, true, false, true, true);
+        return w5 ? RR_PK(COUNT_OFF, true, false, true, false, W5, true) : RR_PK(COUNT_OFF, true);
+    }
+    if (count) return RR_PK(COUNT_REFERENCE, false);
+    if (ref_sem) return w5 ? RR_PK(COUNT_OFF, false, false, true, true, W5, true) : RR_PK(COUNT_OFF, false, false, true, true);
+    return w5 ? RR_PK(COUNT_OFF, false, false, true, false, W5, true) : RR_PK(COUNT_OFF, false);
+}
+#undef RR_PK
+
 // The persistent renderer at path granularity: batches of samples of every slot, each one launch of k_wf_paths that
 // leaves every sample's value in `values` (room for `capacity` paths), and the in-order accumulation of the batch.
 // Allocates nothing: the caller brings the values' memory and the device word the waves claim their paths from.
@@ -1020,41 +1054,14 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     const uint64_t batch = std::min<uint64_t>(most, std::max(a.spt, 1u));
     WfState st{};
     st.thr = values;
-    using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
-    // (a scene without BVH nodes has no visits to skip: its two counting modes are one kernel)
-    // The production builds (no counting): without the semantics switch where it is off (REF_SEM), and for lean scenes
-    // (rr_context::lean_scene) the builds at 5 waves per SIMD instead of 4 that leave out what such scenes do not need (see k_wf_paths).
-    constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
-    const bool ref_sem = ctx->sc.intended == 0u && ctx->sc.book == 0u, w5 = ctx->lean_scene && !ctx->has_triangles;
-    PathsKernel kernel;
-    if (ctx->has_subtrees) {
-        if (count == COUNT_PRODUCTION) kernel = k_wf_paths<COUNT_PRODUCTION, true, true>;
-        else if (count == COUNT_REFERENCE) kernel = k_wf_paths<COUNT_REFERENCE, true, true>;
-        else if (!ref_sem) kernel = ctx->has_general_subtrees ? k_wf_paths<COUNT_OFF, true, true> : k_wf_paths<COUNT_OFF, true, true, false>;
-        else if (ctx->has_general_subtrees)
-            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, true, true>;
-        else
-#ifdef RR_TRI_W4
-            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true, RR_RENDER_WAVES_PER_SIMD, false>;
-#else
-            kernel = w5 ? k_wf_paths<COUNT_OFF, true, true, false, true, W5, true> : k_wf_paths<COUNT_OFF, true, true, false, true, W5, false>;
-#endif
-        // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
-        // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
-    } else if (ctx->prog_vector_ops) {
-        // (without subtrees REF_SEM only concerns shading: the builds that know the book estimator is off do not carry its code)
-        if (count) kernel = k_wf_paths<COUNT_REFERENCE, true>;
-        else if (ref_sem) kernel = w5 ? k_wf_paths<COUNT_OFF, true, false, true, true, W5, true> : k_wf_paths<COUNT_OFF, true, false, true, true>;
-        else kernel = w5 ? k_wf_paths<COUNT_OFF, true, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, true>;
-    } else {
-        if (count) kernel = k_wf_paths<COUNT_REFERENCE, false>;
-        else if (ref_sem) kernel = w5 ? k_wf_paths<COUNT_OFF, false, false, true, true, W5, true> : k_wf_paths<COUNT_OFF, false, false, true, true>;
-        else kernel = w5 ? k_wf_paths<COUNT_OFF, false, false, true, false, W5, true> : k_wf_paths<COUNT_OFF, false>;
-    }
+    const PathsChoice choice = choose_paths_kernel(ctx, count);
+    const PathsKernel kernel = choice.fn;
+    // the kernel rr_scene_specialize compiled for this scene's program stands in for the interpreter's build of the same name
+    const bool jit = count == COUNT_OFF && ctx->jit_fn != nullptr && ctx->jit_targs == choice.targs;
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
     const size_t lds = static_cast<size_t>(ctx->info.stack_words) * 256u * 4u + (ctx->has_subtrees ? 4u * PARK_LDS_WORDS_PER_WAVE * 4u : 0u);
     int grid = 0;
-    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid)) return rc;
+    if (int rc = launch_dims(ctx, lds, reinterpret_cast<const void*>(kernel), &grid, jit ? ctx->jit_fn : nullptr)) return rc;
     const uint32_t slot_blocks = (a.n_slots + 255u) / 256u;
     for (uint32_t s0 = 0; s0 < a.spt || s0 == 0; s0 += static_cast<uint32_t>(batch)) {
         a.s0 = s0;
@@ -1068,8 +1075,15 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
             // a wave's share, in steps of 64 paths between 64 and RR_PATHS_CHUNK.
             a.paths_chunk = std::min<uint32_t>(std::max<uint32_t>(a.n_paths / (g * 4u * 16u) / 64u * 64u, 64u), RR_PATHS_CHUNK);
 #endif
-            hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, next_path, counters);
-            HIP_TRY(hipGetLastError());
+            if (jit) {
+                DevScene sc_arg = ctx->sc;
+                float4* values_arg = st.thr;
+                void* params[] = {&sc_arg, &a, &values_arg, &next_path, &counters};
+                HIP_TRY(hipModuleLaunchKernel(ctx->jit_fn, g, 1, 1, 256, 1, 1, static_cast<unsigned int>(lds), stream, params, nullptr));
+            } else {
+                hipLaunchKernelGGL(kernel, dim3(g), dim3(256), lds, stream, ctx->sc, a, st.thr, next_path, counters);
+                HIP_TRY(hipGetLastError());
+            }
         }
         hipLaunchKernelGGL(k_wf_accumulate, dim3(slot_blocks), dim3(256), 0, stream, a, st, sums);
         HIP_TRY(hipGetLastError());
@@ -1102,6 +1116,141 @@ int render_paths(rr_context* ctx, WfArgs a, int count, float* sums, unsigned lon
     if (!ctx->next_item) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->next_item), sizeof(unsigned long long)));
     return render_paths_in(ctx, a, count, sums, counters, stream, static_cast<float4*>(ctx->wf_mem), static_cast<uint64_t>(a.n_slots) * batch,
                            reinterpret_cast<unsigned int*>(ctx->next_item));
+}
+
+// ------------------------------------------------------------------------------------ per-scene compile (rr_scene_specialize)
+// libhiprtc.so, opened the first time a scene is specialised: a host that never asks needs no runtime compiler.
+struct Hiprtc {
+    void* lib = nullptr;
+    std::string why;
+    int (*CreateProgram)(void**, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    int (*AddNameExpression)(void*, const char*) = nullptr;
+    int (*CompileProgram)(void*, int, const char* const*) = nullptr;
+    int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+    int (*GetProgramLog)(void*, char*) = nullptr;
+    int (*GetLoweredName)(void*, const char*, const char**) = nullptr;
+    int (*GetCodeSize)(void*, size_t*) = nullptr;
+    int (*GetCode)(void*, char*) = nullptr;
+    int (*DestroyProgram)(void**) = nullptr;
+    bool ok() const { return lib != nullptr; }
+};
+Hiprtc& hiprtc() {
+    static Hiprtc h;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"}) {
+            h.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h.lib) break;
+        }
+        if (!h.lib) {
+            h.why = std::string("libhiprtc.so cannot be opened: ") + (dlerror() ? dlerror() : "unknown error");
+            return;
+        }
+        auto sym = [&](const char* n) { return dlsym(h.lib, n); };
+        h.CreateProgram = reinterpret_cast<decltype(h.CreateProgram)>(sym("hiprtcCreateProgram"));
+        h.AddNameExpression = reinterpret_cast<decltype(h.AddNameExpression)>(sym("hiprtcAddNameExpression"));
+        h.CompileProgram = reinterpret_cast<decltype(h.CompileProgram)>(sym("hiprtcCompileProgram"));
+        h.GetProgramLogSize = reinterpret_cast<decltype(h.GetProgramLogSize)>(sym("hiprtcGetProgramLogSize"));
+        h.GetProgramLog = reinterpret_cast<decltype(h.GetProgramLog)>(sym("hiprtcGetProgramLog"));
+        h.GetLoweredName = reinterpret_cast<decltype(h.GetLoweredName)>(sym("hiprtcGetLoweredName"));
+        h.GetCodeSize = reinterpret_cast<decltype(h.GetCodeSize)>(sym("hiprtcGetCodeSize"));
+        h.GetCode = reinterpret_cast<decltype(h.GetCode)>(sym("hiprtcGetCode"));
+        h.DestroyProgram = reinterpret_cast<decltype(h.DestroyProgram)>(sym("hiprtcDestroyProgram"));
+        if (!h.CreateProgram || !h.AddNameExpression || !h.CompileProgram || !h.GetProgramLogSize || !h.GetProgramLog || !h.GetLoweredName ||
+            !h.GetCodeSize || !h.GetCode || !h.DestroyProgram) {
+            h.why = "libhiprtc.so lacks an entry point of the runtime compiler";
+            dlclose(h.lib);
+            h.lib = nullptr;
+        }
+    });
+    return h;
+}
+
+// The options of the per-scene compile: those of the library's own build that decide what code a source line becomes
+// (rust_raytracer_amd/build.py: HIPCC_FLAGS; a test holds the two lists together).
+const char* const kJitOptions[] = {"--gpu-architecture=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+constexpr uint32_t RR_JIT_MAX_OPS = 256;      // an unrolled program longer than this is not compiled at all
+constexpr uint32_t RR_JIT_AUTO_MAX_OPS = 64;  // RR_SPECIALIZE_AUTO: nor one longer than this
+
+struct JitCode {
+    std::vector<char> code;
+    std::string lowered;  // the kernel's symbol in the code object
+};
+std::mutex g_jit_mutex;
+std::map<std::string, JitCode> g_jit_cache;  // compiled once per process and (template arguments, program)
+
+// One header of the library without its #include <...> lines (the runtime compiler has no system headers, and needs none).
+std::string without_system_includes(const char* text) {
+    std::string out;
+    for (const char* p = text; *p;) {
+        const char* e = std::strchr(p, '\n');
+        const size_t n = e ? static_cast<size_t>(e - p) + 1 : std::strlen(p);
+        if (!(std::strncmp(p, "#include <", 10) == 0)) out.append(p, n);
+        else out.append("\n");
+        p += n;
+    }
+    return out;
+}
+
+// Compiles k_wf_paths<targs> for the program `words` (eight words per op).  On failure *log holds the compiler's output.
+int jit_compile(const std::string& targs, const std::vector<uint32_t>& words, JitCode* out, std::string* log) {
+    Hiprtc& H = hiprtc();
+    if (!H.ok()) return fail(RR_E_NO_DEVICE, "rr_scene_specialize: " + H.why);
+    const size_t n_ops = words.size() / 8;
+    std::string fixed = "#define RR_FIXED_N_OPS " + std::to_string(n_ops) + "\nconstexpr uint32_t kFixedWords[" + std::to_string(n_ops) + "][8] = {\n";
+    char buf[128];
+    for (size_t i = 0; i < n_ops; ++i) {
+        const uint32_t* w = &words[8 * i];
+        std::snprintf(buf, sizeof(buf), "    {0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu, 0x%08xu},\n", w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+        fixed += buf;
+    }
+    fixed += "};\n";
+    const std::string main_src =
+        "typedef unsigned char uint8_t;\ntypedef unsigned short uint16_t;\ntypedef unsigned int uint32_t;\ntypedef unsigned long long uint64_t;\n"
+        "typedef signed char int8_t;\ntypedef short int16_t;\ntypedef int int32_t;\ntypedef long long int64_t;\ntypedef unsigned long size_t;\n"
+        "#define RR_FIXED_PROGRAM \"rr_fixed_program.inc\"\n"
+        "#include \"rr_device.h\"\nusing namespace rrdev;\n#include \"rr_wavefront.h\"\n"
+        "constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;\n";
+    const std::string dev_h = without_system_includes(rr_src_device_h), wf_h = without_system_includes(rr_src_wavefront_h),
+                      api_h = without_system_includes(rr_src_api_h);
+    const char* headers[] = {dev_h.c_str(), wf_h.c_str(), api_h.c_str(), fixed.c_str()};
+    const char* names[] = {"rr_device.h", "rr_wavefront.h", "rr_hip.h", "rr_fixed_program.inc"};
+    void* prog = nullptr;
+    if (H.CreateProgram(&prog, main_src.c_str(), "rr_scene_kernel.hip", 4, headers, names) != 0) return fail(RR_E_HIP, "rr_scene_specialize: hiprtcCreateProgram failed");
+    const std::string expr = "&k_wf_paths<" + targs + ">";
+    int rc = RR_OK;
+    if (H.AddNameExpression(prog, expr.c_str()) != 0) rc = fail(RR_E_HIP, "rr_scene_specialize: hiprtcAddNameExpression failed");
+    if (rc == RR_OK) {
+        const int cr = H.CompileProgram(prog, static_cast<int>(sizeof(kJitOptions) / sizeof(kJitOptions[0])), kJitOptions);
+        size_t ls = 0;
+        if (H.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+            log->assign(ls, '\0');
+            (void)H.GetProgramLog(prog, &(*log)[0]);
+        }
+        if (cr != 0) rc = fail(RR_E_HIP, "rr_scene_specialize: the per-scene compile failed:\n" + log->substr(0, 4000));
+    }
+    if (rc == RR_OK) {
+        const char* lowered = nullptr;
+        size_t cs = 0;
+        if (H.GetLoweredName(prog, expr.c_str(), &lowered) != 0 || !lowered || H.GetCodeSize(prog, &cs) != 0 || cs == 0) {
+            rc = fail(RR_E_HIP, "rr_scene_specialize: the compiled program has no kernel " + expr);
+        } else {
+            out->lowered = lowered;
+            out->code.resize(cs);
+            if (H.GetCode(prog, out->code.data()) != 0) rc = fail(RR_E_HIP, "rr_scene_specialize: hiprtcGetCode failed");
+        }
+    }
+    (void)H.DestroyProgram(&prog);
+    return rc;
+}
+
+void jit_unload(rr_context* ctx) {
+    if (ctx->jit_mod) (void)hipModuleUnload(ctx->jit_mod);
+    ctx->jit_mod = nullptr;
+    ctx->jit_fn = nullptr;
+    ctx->jit_targs.clear();
+    ctx->info.specialized = 0u;
+    ctx->info.specialize_ms = 0.0f;
 }
 
 }  // namespace
@@ -1161,6 +1310,7 @@ int rr_context_destroy(rr_context* ctx) {
     if (!ctx) return RR_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    jit_unload(ctx);
     ctx->scene_mem.release();
     if (ctx->wf_mem) (void)hipFree(ctx->wf_mem);
     if (ctx->wf_host_count) (void)hipHostFree(ctx->wf_host_count);
@@ -1449,6 +1599,8 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
 
     // ---- upload (replacing any previous scene)
     (void)hipDeviceSynchronize();
+    jit_unload(ctx);  // (a kernel compiled for the previous scene's program)
+    ctx->prog_words.assign(reinterpret_cast<const uint32_t*>(pb.ops.data()), reinterpret_cast<const uint32_t*>(pb.ops.data()) + 8u * n_ops);
     ctx->scene_mem.release();
     ctx->has_scene = false;
     DevScene d{};
@@ -1548,6 +1700,81 @@ int rr_scene_info_get(rr_context* ctx, rr_scene_info* out) {
     *out = ctx->info;
     out->workspace_bytes = ctx->wf_bytes + (ctx->next_item ? sizeof(unsigned long long) : 0u);
     return RR_OK;
+}
+
+int rr_scene_specialize(rr_context* ctx, uint32_t mode) {
+    if (!ctx) return fail(RR_E_INVALID, "rr_scene_specialize: NULL argument");
+    if (!ctx->has_scene) return fail(RR_E_NO_SCENE, "rr_scene_specialize: no scene uploaded");
+    if (mode > RR_SPECIALIZE_OFF) return fail(RR_E_INVALID, "rr_scene_specialize: unknown mode");
+    if (int rc = set_device(ctx)) return rc;
+    if (mode == RR_SPECIALIZE_OFF) {
+        HIP_TRY(hipDeviceSynchronize());
+        jit_unload(ctx);
+        return RR_OK;
+    }
+    const uint32_t n_ops = static_cast<uint32_t>(ctx->prog_words.size() / 8);
+    if (mode == RR_SPECIALIZE_AUTO && (ctx->has_subtrees || n_ops == 0 || n_ops > RR_JIT_AUTO_MAX_OPS)) return RR_OK;  // not expected to pay
+    if (n_ops == 0) return RR_OK;  // (an empty scene has no program to compile)
+    if (n_ops > RR_JIT_MAX_OPS)
+        return fail(RR_E_LIMIT, "rr_scene_specialize: a program of " + std::to_string(n_ops) + " ops is not unrolled (at most " + std::to_string(RR_JIT_MAX_OPS) + ")");
+    const PathsChoice choice = choose_paths_kernel(ctx, COUNT_OFF);
+    if (ctx->jit_fn && ctx->jit_targs == choice.targs) return RR_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string key = std::string(choice.targs) + "|";
+    key.append(reinterpret_cast<const char*>(ctx->prog_words.data()), ctx->prog_words.size() * sizeof(uint32_t));
+    JitCode code;
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        auto it = g_jit_cache.find(key);
+        if (it == g_jit_cache.end()) {
+            std::string log;
+            if (int rc = jit_compile(choice.targs, ctx->prog_words, &code, &log)) return rc;
+            g_jit_cache[key] = code;
+        } else {
+            code = it->second;
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    jit_unload(ctx);
+    hipModule_t mod = nullptr;
+    HIP_TRY(hipModuleLoadData(&mod, code.code.data()));
+    hipFunction_t fn = nullptr;
+    const hipError_t e = hipModuleGetFunction(&fn, mod, code.lowered.c_str());
+    if (e != hipSuccess || !fn) {
+        (void)hipModuleUnload(mod);
+        return fail(RR_E_HIP, std::string("rr_scene_specialize: the code object has no function ") + code.lowered);
+    }
+    ctx->jit_mod = mod;
+    ctx->jit_fn = fn;
+    ctx->jit_targs = choice.targs;
+    ctx->info.specialized = 1u;
+    ctx->info.specialize_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RR_OK;
+}
+
+/* The options rr_scene_specialize compiles with, space separated (for checks against the library's own build). */
+const char* rr_specialize_options(void) {
+    static const std::string joined = [] {
+        std::string j;
+        for (const char* o : kJitOptions) j += (j.empty() ? "" : " ") + std::string(o);
+        return j;
+    }();
+    return joined.c_str();
+}
+
+/* Compiles a two-op program (a sphere and a rect) with the runtime compiler, without a device: a check that the device
+ * sources inside the library still compile that way.  ms: the time the compile took. */
+int rr_specialize_selftest(float* ms) {
+    std::vector<uint32_t> words(16, 0u);
+    words[0] = OP_SPHERE, words[1] = 0u, words[5] = 0x3f800000u;            // unit sphere at the origin
+    words[8] = OP_RECT_XZ, words[9] = 0u, words[11] = 0x3f800000u, words[13] = 0x3f800000u, words[14] = 0x40000000u;
+    JitCode code;
+    std::string log;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = jit_compile("COUNT_OFF, false, false, true, true, W5, true", words, &code, &log);
+    if (ms) *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == RR_OK && (code.code.empty() || code.lowered.empty())) return fail(RR_E_HIP, "rr_specialize_selftest: empty code object");
+    return rc;
 }
 
 int rr_primary_hits(rr_context* ctx, uint32_t n, const float* rays, float t_min, float t_max, uint64_t seed, rr_hit* out) {
@@ -2047,6 +2274,13 @@ int rr_multi_scene_upload(rr_multi* m, const rr_flat_scene* scene) {
     if (!m || !scene) return fail(RR_E_INVALID, "rr_multi_scene_upload: NULL argument");
     for (rr_multi::Dev& d : m->devs)
         if (int rc = rr_scene_upload(d.ctx, scene)) return rc;
+    return RR_OK;
+}
+
+int rr_multi_scene_specialize(rr_multi* m, uint32_t mode) {
+    if (!m) return fail(RR_E_INVALID, "rr_multi_scene_specialize: NULL argument");
+    for (rr_multi::Dev& d : m->devs)  // (the first device's call compiles; the others find the code object in the process's table)
+        if (int rc = rr_scene_specialize(d.ctx, mode)) return rc;
     return RR_OK;
 }
 

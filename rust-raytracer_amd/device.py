@@ -79,7 +79,15 @@ class Context:
         return dict(stack_words=i.stack_words, max_inst_depth=i.max_inst_depth, device_bytes=i.device_bytes,
                     n_prims=i.n_prims, wavefront=bool(i.wavefront), bvh_nodes_by_class=list(i.bvh_nodes_by_class),
                     subtree_ops=list(i.subtree_ops), wide_nodes=bool(i.wide_nodes),
-                    workspace_bytes=i.workspace_bytes)
+                    workspace_bytes=i.workspace_bytes, specialized=bool(i.specialized), specialize_ms=float(i.specialize_ms))
+
+    SPECIALIZE = {"auto": abi.SPECIALIZE_AUTO, "always": abi.SPECIALIZE_ALWAYS, "off": abi.SPECIALIZE_OFF}
+
+    def specialize(self, mode="auto"):
+        """rr_scene_specialize: compile the path kernel for the uploaded scene's program ("auto": only where it is expected to
+        pay, "always", "off": back to the interpreter).  Returns info()."""
+        _check(self._l.rr_scene_specialize(self._h, self.SPECIALIZE[mode]))
+        return self.info()
 
     def primary_hits(self, rays, t_min=0.001, t_max=3.40282347e38, seed=0):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
@@ -167,6 +175,9 @@ class MultiContext:
 
     def upload(self, flat):
         _check(self._l.rr_multi_scene_upload(self._h, C.byref(flat)))
+
+    def specialize(self, mode="auto"):
+        _check(self._l.rr_multi_scene_specialize(self._h, Context.SPECIALIZE[mode]))
 
     def render(self, job, split=abi.SPLIT_SLICES):
         """The whole job `job` (all slices, all rows) -> dict(rgb8, resolved, linear, counters) in host arrays."""
