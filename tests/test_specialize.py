@@ -158,3 +158,33 @@ def test_in_process_multi_device_route_specializes_every_device():
     for k in ("rgb8", "resolved", "linear"):
         assert np.array_equal(want[k], got[k], equal_nan=True)
     mc.close()
+
+
+@pytest.mark.gpu
+def test_long_programs_are_left_to_the_interpreter(gpu_ctx):
+    """A scene of 300 top-level spheres is a program of 300 ops: AUTO declines (its limit is 64 unrolled ops), ALWAYS reports
+    the limit (256) instead of starting a compile of that size; a 40-op scene is compiled and renders the same bits."""
+    def scene(n):
+        b = host.SceneBuilder(5)
+        m = b.lambertian(b.solid_color((0.6, 0.5, 0.4)))
+        rng = np.random.default_rng(n)
+        for c in rng.uniform(-20, 20, (n, 3)):
+            b.add(b.sphere(c, 1.5, m))
+        b.set_lights(b.xzrect(-5, 5, -5, 5, 30.0, b.emissive((4, 4, 4))))
+        b.set_camera((0, 0, -70), (0, 0, 0), (0, 1, 0), 40.0, 0.0, 10.0, 1.0)
+        b.set_background((0.5, 0.6, 0.9))
+        return b, b.flatten()
+
+    b, flat = scene(300)
+    gpu_ctx.upload(flat)
+    assert not gpu_ctx.specialize("auto")["specialized"]
+    with pytest.raises(Exception, match="not unrolled"):
+        gpu_ctx.specialize("always")
+    assert not gpu_ctx.info()["specialized"]
+    b, flat = scene(40)
+    gpu_ctx.upload(flat)
+    p = device.make_params(64, 48, 8, n_slices=2, max_depth=8, seed=1)
+    want = _images(gpu_ctx, p)
+    assert gpu_ctx.specialize("auto")["specialized"]
+    _assert_same(_images(gpu_ctx, p), want)
+    gpu_ctx.specialize("off")
