@@ -394,7 +394,11 @@ def run_ranks(args, world, rank):
     ctx = device.Context(local_rank)
     info = ctx.upload(flat)
     if args.specialize != "off":
-        info = ctx.specialize(args.specialize)
+        try:
+            info = ctx.specialize(args.specialize)
+        except Exception as e:  # (no runtime compiler on this host: the interpreter renders, and the line says specialized: false)
+            print(f"# rr_scene_specialize failed, rendering with the interpreter: {e}", file=sys.stderr, flush=True)
+            info = ctx.info()
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearsal else dev  # where the small tensors of the bookkeeping collectives live
     stream = torch.cuda.current_stream().cuda_stream
