@@ -125,7 +125,8 @@ def cpu_baseline_run(flat, width, height, depth, seed, threads):
     h = max(1, min(height, round(height * w / width)))
 
     def timed(spt):
-        p = O.make_params(w, h, threads * spt, n_slices=threads, max_depth=depth, seed=seed)
+        # (the reference's walk: every path to its end, dead or not, render.rs:29-34 -- it is the reference that is being timed)
+        p = O.make_params(w, h, threads * spt, n_slices=threads, max_depth=depth, seed=seed, flags=128)
         t0 = time.perf_counter()
         r = O.render(flat, p, n_threads=threads, counters=True)
         return time.perf_counter() - t0, r
@@ -160,7 +161,8 @@ def cpu_baseline(flat, width, height, depth, seed):
     model, mhz = cpu_info()
     out.update({
         "cores_available": available, "cpu_quota": quota, "cpu_model": model, "cpu_mhz_median": mhz,
-        "note": "C++ restatement of the reference (no per-hit Material clones, Box<PDF> allocations or atlas mutex), "
+        "note": "C++ restatement of the reference, walking every path to its end as it does (RR_FLAG_TRACE_DEAD_PATHS), without its "
+                "per-hit Material clones, Box<PDF> allocations or atlas mutex, "
                 "so faster than the Rust binary would be: GPU/CPU ratios against it are conservative; one thread per core the "
                 "process may use (affinity mask cut to the cgroup CPU quota), median of three runs",
     })
@@ -207,6 +209,9 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpus", action="store_true",
                     help="REHEARSAL, not a measurement of N GPUs: rank r renders on GPU r %% (GPUs visible), so that the N-rank code runs on a "
                          "box with fewer GPUs; needs --backend gloo (RCCL refuses two ranks on one GPU); the line says n_gpus = GPUs used")
+    ap.add_argument("--trace-dead-paths", action="store_true",
+                    help="RR_FLAG_TRACE_DEAD_PATHS: walk paths on after their throughput has become exactly zero, as the reference does "
+                         "(the default ends them there: same samples unless the rest of the walk meets a NaN)")
     ap.add_argument("--specialize", default="auto", choices=["auto", "always", "off"],
                     help="rr_scene_specialize after the upload (outside the timed region, like the upload): auto = only programs without BVH subtrees")
     ap.add_argument("--launch-check", action="store_true",
@@ -271,6 +276,8 @@ def default_partition(world, n_slices):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.trace_dead_paths:
+        args.flags |= 128  # RR_FLAG_TRACE_DEAD_PATHS
     in_world = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -500,7 +507,7 @@ def run_ranks(args, world, rank):
             Wc, Hc = max(16, int(W * scale)), max(16, int(H * scale))
             for label, flag in (("production", abi.FLAG_COUNT_PRODUCTION), ("reference_order", abi.FLAG_COUNTERS)):
                 pc = device.make_params(Wc, Hc, K * 4, n_slices=K, max_depth=depth, seed=args.seed,
-                                        flags=flag | (args.flags & (abi.FLAG_PERSISTENT | abi.FLAG_WAVEFRONT | abi.FLAG_PATHS)))
+                                        flags=flag | (args.flags & (abi.FLAG_PERSISTENT | abi.FLAG_WAVEFRONT | abi.FLAG_PATHS | abi.FLAG_TRACE_DEAD_PATHS)))
                 c2 = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=dev)
                 cs = torch.empty((K, Hc, Wc, 3), dtype=torch.float32, device=dev)
                 ctx.render_device(pc, cs.data_ptr(), None, None, c2.data_ptr(), stream)
@@ -573,7 +580,10 @@ def run_ranks(args, world, rank):
                        "max_depth": depth, "parallelism": f"{partition} x{world} ({comb.bands} bands x {comb.groups} slice groups)"
                                                            + (f"; REHEARSAL: {world} ranks share {gpus_used} GPU(s), images combined over gloo through the host"
                                                               if rehearsal else ""),
-                       "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "bvh": args.bvh, "stack_words": info["stack_words"],
+                       "seed": args.seed, "flags": args.flags, "semantics": args.semantics, "bvh": args.bvh,
+                       "dead_paths": ("walked to their end, as the reference does (RR_FLAG_TRACE_DEAD_PATHS)" if args.flags & 128
+                                      else "ended where their throughput becomes exactly zero (the library's default)"),
+                       "stack_words": info["stack_words"],
                        "scene_bytes": info["device_bytes"], "specialized": info["specialized"],
                        "specialize_ms": round(info["specialize_ms"], 1)},
             "mrays_per_s": round(total_rays / elapsed / 1e6, 3),

@@ -655,7 +655,13 @@ V3 lights_random(const rr_flat_scene& s, V3 origin, Philox& g) {
 struct PathKey {
     uint64_t seed;
     uint32_t pixel, sample;
+    bool trace_dead;  // RR_FLAG_TRACE_DEAD_PATHS: the reference's walk; without it a call whose weight for what follows is exactly zero returns at once
 };
+
+// The library's default (include/rr_hip.h, RR_FLAG_TRACE_DEAD_PATHS): once the factor a ray_color call multiplies the rest of its
+// path by is exactly zero in every channel, the rest is not walked and the call returns what it emitted.  The reference walks
+// on (render.rs:29-34) and adds 0 * li: the same value unless li is NaN or infinite.  A NaN factor is not zero.
+static bool dead(const V3& f) { return f.x == 0.0f && f.y == 0.0f && f.z == 0.0f; }
 
 V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t bounce, const PathKey& key, rr_counters* cnt) {
     if (depth == 0) return mk(0, 0, 0);  // render.rs:16-18
@@ -673,6 +679,7 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
     if (!scatter(s, m, r, rec, g, attenuation, book, sdir)) return emitted;
     if (book && m.type != RR_MAT_LAMBERTIAN) {  // RR_SEMANTICS_BOOK_ESTIMATOR: a specular material's own ray, weighted by its attenuation alone
         Ray specular{rec.p, sdir, r.tm};
+        if (!key.trace_dead && dead(attenuation)) return emitted;
         return emitted + attenuation * ray_color(s, specular, depth - 1, bounce + 1, key, cnt);
     }
     // render.rs:29-34
@@ -687,6 +694,7 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
         float cs = dot(rec.n, unit(dir));
         sp = cs < 0.0f ? 0.0f : cs / PI;
     }
+    if (!key.trace_dead && dead(attenuation * sp / pdf_val)) return emitted;
     V3 li = ray_color(s, scattered, depth - 1, bounce + 1, key, cnt);
     return emitted + attenuation * sp * li / pdf_val;
 }
@@ -706,7 +714,7 @@ Ray camera_ray(const rr_camera& cam, float u, float v, Philox& g) {  // camera.r
 // One sample of pixel (i, j) with j counted up from the bottom row (render.rs:95-100).
 V3 sample_pixel(const rr_flat_scene& s, const rr_render_params& p, uint32_t i, uint32_t j, uint32_t sample, rr_counters* cnt) {
     const uint32_t row = p.height - 1 - j;
-    PathKey key{p.seed, row * p.width + i, sample};
+    PathKey key{p.seed, row * p.width + i, sample, (p.flags & RR_FLAG_TRACE_DEAD_PATHS) != 0u};
     Philox g;
     g.start(key.seed, key.pixel, key.sample, CAMERA_BOUNCE);
     float u = (float(i) + g.random()) / (float(p.width) - 1.0f);

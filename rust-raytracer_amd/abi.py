@@ -25,6 +25,7 @@ FLAG_NO_FINISH_KERNEL = 8
 FLAG_PATHS = 16
 FLAG_COUNT_PRODUCTION = 32
 FLAG_NARROW_NODES = 64
+FLAG_TRACE_DEAD_PATHS = 128
 N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304

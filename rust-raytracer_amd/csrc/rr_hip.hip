@@ -52,6 +52,7 @@ struct RenderArgs {
     uint32_t slice_out;     // index of that slice inside the output buffer
     uint32_t max_depth;
     uint32_t sample_offset;
+    uint32_t trace_dead;    // RR_FLAG_TRACE_DEAD_PATHS: paths go on after their throughput has become zero (see dead_path)
     uint64_t seed;
     unsigned long long* next_item;  // the first work item no wave has claimed yet (zero at launch)
 };
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(256, RR_RENDER_WAVES_PER_SIMD) k_render(DevSce
                 thr = thr * b.value;
                 depth_left -= 1;
                 bounce += 1;
+                if (a.trace_dead == 0u && dead_path(thr)) go_on = false;  // (terminal is 0: the sample's value is 0)
             } else {
                 terminal = b.value;
             }
@@ -1883,6 +1885,7 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
         w.spt = spt;
         w.max_depth = p->max_depth;
         w.sample_offset = p->sample_offset;
+        w.trace_dead = (p->flags & RR_FLAG_TRACE_DEAD_PATHS) ? 1u : 0u;
         w.seed = p->seed;
         // slices go through in groups of at most 2^27 slots (72 bytes of path state and queues each); without allocations, of
         // as many slots as the static scratch holds sample values for
@@ -1935,6 +1938,7 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
     a.padded_pixels = a.tiles_x * ((rows + 7u) / 8u) * 64u;
     a.max_depth = p->max_depth;
     a.sample_offset = p->sample_offset;
+    a.trace_dead = (p->flags & RR_FLAG_TRACE_DEAD_PATHS) ? 1u : 0u;
     a.seed = p->seed;
     // Slices are rendered in groups so that one launch stays within about 2^31 samples.
     const uint64_t samples_per_slice = static_cast<uint64_t>(p->width) * rows * std::max(spt, 1u);

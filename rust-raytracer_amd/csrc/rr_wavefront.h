@@ -76,6 +76,7 @@ struct WfArgs {
     uint32_t strip_pixels; // wavefront pipeline: paths are numbered strip by strip (see wf_path_key); 0: sample-major over the whole band
     uint32_t pass_slices;  // n_slots / n_pixels: slices in this pass
     uint32_t n_sub;        // (samples in this batch) * pass_slices: the paths of one pixel in this batch
+    uint32_t trace_dead;   // RR_FLAG_TRACE_DEAD_PATHS: paths go on after their throughput has become zero (see dead_path)
     uint64_t seed;
 };
 
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
                 depth_left -= 1;
                 bounce += 1;
                 if (PARK) draws = 0;
+                if (a.trace_dead == 0u && dead_path(thr)) go_on = false;  // (terminal is 0: the sample's value is 0)
             } else {
                 terminal = b.value;
             }
@@ -538,10 +540,14 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
 #endif
                 if (keep) {
                     thr = thr * b.value;
-                    depth_left -= 1;
-                    st.ray_o[p] = make_float4(b.o.x, b.o.y, b.o.z, time);
-                    st.ray_d[p] = make_float4(b.d.x, b.d.y, b.d.z, __uint_as_float(depth_left));
-                    st.thr[p] = make_float4(thr.x, thr.y, thr.z, 0.f);
+                    if (a.trace_dead == 0u && dead_path(thr)) {
+                        keep = false;  // (terminal stays 0: the sample's value is 0)
+                    } else {
+                        depth_left -= 1;
+                        st.ray_o[p] = make_float4(b.o.x, b.o.y, b.o.z, time);
+                        st.ray_d[p] = make_float4(b.d.x, b.d.y, b.d.z, __uint_as_float(depth_left));
+                        st.thr[p] = make_float4(thr.x, thr.y, thr.z, 0.f);
+                    }
                 } else {
                     terminal = b.value;
                 }
@@ -662,6 +668,7 @@ __global__ void __launch_bounds__(256, RR_WF_FINISH_WAVES_PER_SIMD) k_wf_finish(
                 thr = thr * b.value;
                 depth_left -= 1;
                 draws = 0;
+                if (a.trace_dead == 0u && dead_path(thr)) go_on = false;  // (terminal is 0: the sample's value is 0)
             } else {
                 terminal = b.value;
             }

@@ -140,6 +140,10 @@ def test_sah_tree_is_a_labelled_option_that_only_accelerates(built):
 
 
 # ------------------------------------------------------------ whole paths
+# The fixtures are the reference's walk, dead paths included (render.rs:29-34): the renders compared with them ask for it.
+TRACE = 128  # RR_FLAG_TRACE_DEAD_PATHS (include/rr_hip.h)
+
+
 def _paths_fixture():
     import golden_paths as GP
     fx = np.load(os.path.join(G.GOLDEN_DIR, "paths_box.npz"))
@@ -170,7 +174,7 @@ def test_cpp_oracle_paths_match_the_numpy_restatement(built):
     GP, gold = _paths_fixture()
     b, flat = GP.build_host()
     R = GP.RENDER
-    p = O.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    p = O.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"], flags=TRACE)
     got = O.render(flat, p, n_threads=4)["slice_sums"]
     compare_samples(got, gold, 0.99)
     both = ~np.isnan(got) & ~np.isnan(gold)
@@ -189,7 +193,7 @@ def test_cpp_oracle_paths_under_the_book_semantics_match_the_numpy_restatement(b
     b, flat = GP.build_host(book=True)
     assert flat.n_lights == 3 and flat.lights[0].is_xzrect == 1 and flat.lights[2].is_xzrect == 0
     R = GP.RENDER
-    p = O.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    p = O.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"], flags=TRACE)
     got = O.render(flat, p, n_threads=4)["slice_sums"]
     compare_samples(got, gold, 0.99)
     both = ~np.isnan(got) & ~np.isnan(gold)
@@ -205,7 +209,7 @@ def test_cpp_oracle_nan_samples_match_the_numpy_restatement(built):
     GP, gold = _nolight_fixture()
     b, flat = GP.build_host(light=False)
     R, N = GP.RENDER, GP.NOLIGHT
-    p = O.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    p = O.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"], flags=TRACE)
     got = O.render(flat, p, n_threads=4)["slice_sums"]
     assert 0.1 < np.isnan(gold).mean() < 0.9
     compare_samples(got, gold, 0.99)

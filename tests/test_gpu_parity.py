@@ -484,16 +484,17 @@ def test_paths_match_the_numpy_restatement(gpu_ctx):
     b, flat = GP.build_host()
     gpu_ctx.upload(flat)
     R = GP.RENDER
-    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT):
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_PERSISTENT, abi.FLAG_PATHS):  # (the fixtures are the reference's walk, dead paths included)
         got = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"],
-                                                flags=flags))["slice_sums"]
+                                                flags=flags | abi.FLAG_TRACE_DEAD_PATHS))["slice_sums"]
         compare_samples(got, gold, 0.985)
     from test_golden_cpu import _nolight_fixture
     GP, gold = _nolight_fixture()  # an empty list as `lights`: the NaN samples of render.rs:34
     b, flat = GP.build_host(light=False)
     gpu_ctx.upload(flat)
     N = GP.NOLIGHT
-    got = gpu_ctx.render(device.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"]))["slice_sums"]
+    got = gpu_ctx.render(device.make_params(N["W"], N["H"], N["spp"], n_slices=N["spp"], max_depth=R["max_depth"], seed=R["seed"],
+                                            flags=abi.FLAG_TRACE_DEAD_PATHS))["slice_sums"]
     compare_samples(got, gold, 0.985)
 
 
@@ -967,7 +968,9 @@ def test_full_size_cornell_configuration(gpu_ctx):
     p = device.make_params(600, 600, 1000, n_slices=8, max_depth=200, seed=1)
     r = gpu_ctx.render(p, slice_sums=False)
     assert r["counters"]["samples"] == 600 * 600 * 1000
-    assert 2.5 < r["counters"]["rays"] / r["counters"]["samples"] < 3.5
+    assert 2.2 < r["counters"]["rays"] / r["counters"]["samples"] < 2.7  # (2.9 with dead paths walked to their end, as the reference does)
+    t = gpu_ctx.render(device.make_params(600, 600, 64, n_slices=8, max_depth=200, seed=1, flags=abi.FLAG_TRACE_DEAD_PATHS), slice_sums=False)
+    assert 2.7 < t["counters"]["rays"] / t["counters"]["samples"] < 3.2
     assert np.isfinite(r["linear"]).all() and r["rgb8"].max() == 255
     ref = O.render(flat, O.make_params(600, 600, 16, n_slices=8, max_depth=200, seed=77), n_threads=16)
     m_gpu, m_ref = r["linear"].mean() / 1000.0, ref["linear"].mean() / 16.0
@@ -992,7 +995,7 @@ def test_full_size_bvh_configurations(gpu_ctx, name, depth, spp):
     kw = dict(n_slices=8, max_depth=depth, seed=1)
     whole = gpu_ctx.render(device.make_params(800, 800, spp, **kw), slice_sums=False)
     assert whole["counters"]["samples"] == 800 * 800 * spp
-    assert 1.5 < whole["counters"]["rays"] / whole["counters"]["samples"] < 5.0
+    assert 1.2 < whole["counters"]["rays"] / whole["counters"]["samples"] < 5.0  # (final_scene: 1.29; 3.23 with dead paths walked to their end)
     assert np.isfinite(whole["linear"]).all() and whole["rgb8"].max() > 100
     again = gpu_ctx.render(device.make_params(800, 800, spp, **kw), slice_sums=False)
     assert np.array_equal(whole["rgb8"], again["rgb8"]) and np.array_equal(whole["linear"], again["linear"])
@@ -1124,11 +1127,13 @@ def test_book_semantics_match_the_fixture_the_oracle_and_every_kernel_form(gpu_c
     info = gpu_ctx.upload(flat)
     R = GP.RENDER
     kw = dict(n_slices=R["spp"], max_depth=R["max_depth"], seed=R["seed"])
+    full = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], flags=abi.FLAG_TRACE_DEAD_PATHS, **kw))
+    compare_samples(full["slice_sums"], fx["samples"], 0.985)  # (the fixture is the full walk, dead paths included)
     got = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], **kw))
-    compare_samples(got["slice_sums"], fx["samples"], 0.985)
     want = O.render(flat, O.make_params(R["W"], R["H"], R["spp"], **kw), n_threads=8, counters=True)
     compare_samples(got["slice_sums"], want["slice_sums"], 0.985)
-    assert abs(got["counters"]["rays"] - want["counters"]["rays"]) < 0.01 * want["counters"]["rays"]
+    # (16 000 rays: the few paths a last-bit difference in sin/cos sends elsewhere are a percent of them)
+    assert abs(got["counters"]["rays"] - want["counters"]["rays"]) < 0.02 * want["counters"]["rays"]
     for flags in (abi.FLAG_PATHS, abi.FLAG_PERSISTENT, abi.FLAG_WAVEFRONT, abi.FLAG_WAVEFRONT | abi.FLAG_NO_FINISH_KERNEL, abi.FLAG_COUNTERS):
         other = gpu_ctx.render(device.make_params(R["W"], R["H"], R["spp"], flags=flags, **kw))
         assert np.array_equal(got["slice_sums"], other["slice_sums"], equal_nan=True), flags
