@@ -299,7 +299,8 @@ typedef struct rr_render_params {
  * NaN or an infinity (0 * NaN = NaN: the 0/0 of render.rs:34 where a surface's mixture pdf is 0), which the reference turns into
  * one zeroed pixel of one slice (render.rs:102-119); with a light the library can sample that is a few samples in 10^8
  * (tests/test_dead_paths.py).  This flag makes the kernels walk dead paths to their end exactly as the reference
- * does.  The CPU oracle honours the same flag.  A NaN throughput is not zero: such paths always go on.                      */
+ * does.  The CPU oracle honours the same flag.  A throughput that is NaN in every channel ends a path as well, and that is
+ * exact: NaN times whatever follows is NaN, which is what the ended path leaves as its sample.                              */
 #define RR_FLAG_TRACE_DEAD_PATHS 128u
 
 typedef struct rr_counters {

@@ -14,6 +14,10 @@ pdf.rs:5-70, texture.rs:66-103) over the path random streams rr_oracle.cpp uses.
 
 Pure-Python loops: use for small cases only (a few thousand rays).
 
+ray_color here is the reference's walk: every path to its end, also after its weight has become exactly zero
+(render.rs:29-34).  The library and rr_oracle.cpp end such paths by default (RR_FLAG_TRACE_DEAD_PATHS in include/rr_hip.h);
+comparisons with the fixtures this file writes set that flag.
+
 PARITY UNPINNED with respect to the Rust binary: the reference has no tests or golden
 vectors and cannot be built here; this file and rr_oracle.cpp are two readings of the same
 source that are checked against each other and against analytic answers.

@@ -660,8 +660,10 @@ struct PathKey {
 
 // The library's default (include/rr_hip.h, RR_FLAG_TRACE_DEAD_PATHS): once the factor a ray_color call multiplies the rest of its
 // path by is exactly zero in every channel, the rest is not walked and the call returns what it emitted.  The reference walks
-// on (render.rs:29-34) and adds 0 * li: the same value unless li is NaN or infinite.  A NaN factor is not zero.
+// on (render.rs:29-34) and adds 0 * li: the same value unless li is NaN or infinite.  A factor that is NaN in every channel
+// ends the walk too, exactly: NaN * li is NaN whatever li is, and that is what the call returns.
 static bool dead(const V3& f) { return f.x == 0.0f && f.y == 0.0f && f.z == 0.0f; }
+static bool all_nan(const V3& f) { return f.x != f.x && f.y != f.y && f.z != f.z; }
 
 V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t bounce, const PathKey& key, rr_counters* cnt) {
     if (depth == 0) return mk(0, 0, 0);  // render.rs:16-18
@@ -680,6 +682,7 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
     if (book && m.type != RR_MAT_LAMBERTIAN) {  // RR_SEMANTICS_BOOK_ESTIMATOR: a specular material's own ray, weighted by its attenuation alone
         Ray specular{rec.p, sdir, r.tm};
         if (!key.trace_dead && dead(attenuation)) return emitted;
+        if (!key.trace_dead && all_nan(attenuation)) return attenuation;
         return emitted + attenuation * ray_color(s, specular, depth - 1, bounce + 1, key, cnt);
     }
     // render.rs:29-34
@@ -695,6 +698,7 @@ V3 ray_color(const rr_flat_scene& s, const Ray& r, uint32_t depth, uint32_t boun
         sp = cs < 0.0f ? 0.0f : cs / PI;
     }
     if (!key.trace_dead && dead(attenuation * sp / pdf_val)) return emitted;
+    if (!key.trace_dead && all_nan(attenuation * sp / pdf_val)) return attenuation * sp / pdf_val;  // (emitted + NaN)
     V3 li = ray_color(s, scattered, depth - 1, bounce + 1, key, cnt);
     return emitted + attenuation * sp * li / pdf_val;
 }

@@ -2063,8 +2063,11 @@ __device__ __forceinline__ f3 refract3(f3 uv, f3 n, float etai_over_etat) {  // 
 // its 0; the kernels end it here and add the 0 at once, unless RR_FLAG_TRACE_DEAD_PATHS asks for the reference's walk.
 // The two differ only where the rest of the walk would have met a NaN or an infinity (0 * NaN = NaN: the 0/0 of render.rs:34
 // at a surface hit whose mixture pdf is 0), which the reference turns into a zeroed pixel of that slice (render.rs:102-119).
-// A throughput that is NaN is not zero: such a path goes on as it does in the reference.
-__device__ __forceinline__ bool dead_path(f3 thr) { return thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f; }
+// A throughput that is NaN in every channel ends a path as well, and exactly: NaN times whatever follows is NaN, which is what
+// the ended path leaves as its sample (NaN * 0).  Anything else (one channel zero, an infinity) goes on.
+__device__ __forceinline__ bool dead_path(f3 thr) {
+    return (thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f) || (thr.x != thr.x && thr.y != thr.y && thr.z != thr.z);
+}
 
 struct Bounce {
     f3 o, d;
