@@ -1403,12 +1403,17 @@ struct ParkArea {        // wave-uniform
 // `simple`: the visit is of a simple subtree, inside which the machine's ray and t_min are the program's at that op (nothing
 // below changes the ray space or the range's lower end): they are saved once, and after a load the machine's are the
 // program's *registers*, not copies the compiler must keep beside them through the loop of the machine.
-__device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, const ProgState& s, const Trav& m, bool open_medium, bool simple) {
+// `guests`: simple visits also keep the visit's culling margin (in a word a simple visit does not use): a lane that takes steps
+// as a guest of another visit needs its own.
+__device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, const ProgState& s, const Trav& m, bool open_medium, bool simple,
+                                          bool guests = false) {
     uint32_t* w = pa.slots + slot;
     if (!simple) {
         const float v[7] = {m.o.x, m.o.y, m.o.z, m.d.x, m.d.y, m.d.z, m.tmin};
 #pragma unroll
         for (uint32_t k = 0; k < 7; ++k) w[k * PARK_SLOTS] = __float_as_uint(v[k]);
+    } else if (guests) {
+        w[0] = __float_as_uint(m.margin);
     }
     const float v[8] = {m.tmax, s.o.x, s.o.y, s.o.z, s.d.x, s.d.y, s.d.z, s.tmin};
 #pragma unroll
@@ -1421,7 +1426,8 @@ __device__ __forceinline__ void park_save(const ParkArea& pa, uint32_t slot, con
     w[19 * PARK_SLOTS] = m.node;
     w[20 * PARK_SLOTS] = m.sp | (m.hitf ? 1u << 31 : 0u) | (s.live ? 1u << 30 : 0u);
 }
-__device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, ProgState& s, Trav& m, bool open_medium, bool simple) {
+__device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, ProgState& s, Trav& m, bool open_medium, bool simple,
+                                          bool guests = false) {
     const uint32_t* w = pa.slots + slot;
     float v[8];
 #pragma unroll
@@ -1435,6 +1441,8 @@ __device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, Pro
         for (uint32_t k = 0; k < 7; ++k) u[k] = __uint_as_float(w[k * PARK_SLOTS]);
         m.set_ray(mk3(u[0], u[1], u[2]), mk3(u[3], u[4], u[5]));  // (1/direction and the culling flag follow from the ray)
         m.tmin = u[6];
+    } else if (guests) {
+        m.margin = __uint_as_float(w[0]);
     }
     if (open_medium) {
         s.m_tmin = __uint_as_float(w[15 * PARK_SLOTS]), s.m_tmax = __uint_as_float(w[16 * PARK_SLOTS]), s.m_t1 = __uint_as_float(w[17 * PARK_SLOTS]);
@@ -1448,9 +1456,11 @@ __device__ __forceinline__ void park_load(const ParkArea& pa, uint32_t slot, Pro
 
 // After a visit of a subtree: lanes whose descent is complete take its result and give their slot back; the others
 // are parked at `this_pc`, in the slot they have or in a free one.  Wave-uniform control flow.
+// `guest` (only in builds with guests): the lane is parked at another op and took steps of its own descent in this visit: it
+// stays parked where it was, finished or not, and only its slot is brought up to date.
 __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Trav& m, uint32_t& slot, bool in, uint32_t this_pc, bool& act,
-                                            bool open_medium, bool simple) {
-    const bool done = in && m.finished();
+                                            bool open_medium, bool simple, bool guests = false, bool guest = false) {
+    const bool done = in && m.finished() && !guest;
     uint64_t fm = RR_BALLOT(done && s.parked);  // slots coming back
     while (fm != 0) {
         const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(fm));
@@ -1473,9 +1483,9 @@ __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Tr
             act = true;
         } else {
             s.parked = true;
-            s.park_pc = this_pc;
+            s.park_pc = guest ? s.park_pc : this_pc;
             act = false;
-            park_save(pa, slot, s, m, open_medium, simple);
+            park_save(pa, slot, s, m, open_medium, simple, guests);
         }
     }
 }
@@ -1488,7 +1498,19 @@ __device__ __forceinline__ void park_settle(ParkArea& pa, ProgState& s, const Tr
 // GENERAL = false builds the interpreter without the general machine (OP_SUBTREE: subtrees with instances, media, lists or
 // moving spheres below BVH nodes), for scenes whose subtrees are all simple: the code a kernel never runs still costs it
 // registers (measured: final_scene +1.4 %, Suzanne +1.7 %).
-template <int COUNT, bool GENERAL = true>
+// GUESTS (builds for scenes with two or more subtrees, all of them simple): lanes parked at ANOTHER subtree take the steps of a
+// visit as well, on their own descent -- their machine state is complete in their slot and their stack is their own; the lanes
+// of a visit that are not in it have nothing to do while it lasts, and a parked path is a lane that sits out the ops and the
+// shading of every turn until its descent is complete.  A guest never prolongs a visit, and its result is taken at its own
+// op, in program order; visits may then be left after RR_GUEST_MIN_STEPS steps, since parked lanes get on elsewhere too.
+// Measured on final_scene (the one benchmark scene with two subtrees; bit-identical): 5 890 -> 5 990 / 5 970 / 5 940 / 5 910
+// Msamples/s with visits left after at least 1 / 2 / 4 / 6 steps; the sphere cluster's visits, 14 % of the kernel's time at 16
+// lanes, shrink, and its rays finish inside the box tree's visits.  As code that every build carried (a first version) it cost
+// the scenes with one subtree 1.6-2.9 %: hence a build of its own.
+#ifndef RR_GUEST_MIN_STEPS
+#define RR_GUEST_MIN_STEPS 1u
+#endif
+template <int COUNT, bool GENERAL = true, bool GUESTS = false>
 __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 wd, float time, float tmin0, float tmax0, bool enabled,
                                                  uint32_t& park, ParkArea& pa, Rng& rng, uint32_t* stk, uint32_t stride, uint32_t park_below,
                                                  uint32_t min_steps, uint32_t leaf_wait, Counts& cnt, float& t_hit, uint32_t& ref_hit) {
@@ -1508,7 +1530,7 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
     Counts& pcnt = cnt;
     // a visit may end with lanes still descending only while there are slots for the ones that have none yet
     auto may_park = [&](bool going, uint32_t n, uint32_t steps) {
-        if (!(n < park_below && steps >= min_steps)) return false;
+        if (!(n < park_below && steps >= (GUESTS ? min(min_steps, RR_GUEST_MIN_STEPS) : min_steps))) return false;
         return static_cast<uint32_t>(__popcll(RR_BALLOT(going && !s.parked))) <= static_cast<uint32_t>(__popc(pa.free_mask));
     };
 #ifdef RR_FIXED_PROGRAM  // (a per-scene build: see struct Op)
@@ -1550,19 +1572,19 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             // that pass descend, on the moves that know nothing but BVH frames and those four kinds of leaves.
             RR_SEC_MARK(cnt, 1);
             const bool rejoin = enabled && s.parked && s.park_pc == this_pc;
-            // (Tried: lanes parked at ANOTHER simple subtree take the steps of this visit as well, on their own descent — their
-            // machine state is complete in their slot and their stack is their own.  Bit-identical, and on final_scene, the one
-            // benchmark scene with two subtrees, the later subtree's visits fell from 3.85 to 2.93 steps per turn: +0.3 %; the
-            // bookkeeping cost scenes with one subtree 1.6-2.9 %.  Few lanes are parked at any time; not kept.)
+            bool guest = GUESTS && enabled && s.parked && s.park_pc != this_pc;
             Trav m;
             m.begin(NONE, s.o, s.d, s.tmin, s.tmax, s.cur);
-            if (rejoin) park_load(pa, slot, s, m, sc.lean == 0u, true);
+            if (rejoin || guest) park_load(pa, slot, s, m, sc.lean == 0u, true, GUESTS);
             if (sc.lean) s.tmin = tmin0, s.live = true;  // (only the medium ops a lean program does not have change them: constants, not registers)
             m.set_ray(s.o, s.d);  // (the lanes that rejoin have their ray from their slot: one set of registers for the program's ray and the machine's)
             m.tmin = s.tmin;
 #ifndef RR_NODE_MARGIN
             constexpr bool SUBTREE_MARGIN = true;
-            m.margin = cull_margin(sc, m.o, mk3(op.f0, op.f1, op.f2), mk3(op.f3, op.f4, op.f5));
+            {
+                const float visit_margin = cull_margin(sc, m.o, mk3(op.f0, op.f1, op.f2), mk3(op.f3, op.f4, op.f5));
+                m.margin = guest ? m.margin : visit_margin;  // (a guest's is the one of its own visit, from its slot)
+            }
 #else
             constexpr bool SUBTREE_MARGIN = false;
 #endif
@@ -1578,7 +1600,10 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
             }
             asm volatile("" ::"s"(left), "s"(right));
             if (enter) node_descend(sc, m, ridx, left, right, cls, stk, stride);
-            const bool in = enter || rejoin;
+            const bool local = enter || rejoin;
+            guest = guest && !m.finished();  // (a guest whose descent is complete waits for its own op)
+            const bool in = local || guest;
+            bool moved = false;  // wave-uniform: the visit took at least one step
             RR_SEC_MARK(cnt, 4);
             RR_SEC_ADD(cnt, this_pc < 4u ? 12 : 13, static_cast<unsigned long long>(__popcll(RR_BALLOT(in))));
             // (a visit of a subtree over triangles counts from a head start: at least TRIANGLE_MIN_STEPS instead of min_steps.
@@ -1589,6 +1614,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 const bool going = in && !m.finished();
                 const uint32_t n = static_cast<uint32_t>(__popcll(RR_BALLOT(going)));
                 if (n == 0 || may_park(going, n, steps)) break;
+                if (GUESTS && !RR_ANY(going && local)) break;  // only guests are left
+                moved = true;
                 // A leaf move is the dearest of the three and usually only a few lanes are at a leaf: those wait, while other
                 // lanes can still move, until they are at least one in `leaf_wait` of the lanes descending (0: nobody waits).
                 if (going) trav_node<COUNT, SUBTREE_MARGIN>(sc, m, stk, stride, cnt);
@@ -1608,7 +1635,8 @@ __device__ __forceinline__ void traverse_parking(const DevScene& sc, f3 wo, f3 w
                 RR_SEC_ADD(cnt, this_pc < 4u ? 14 : 15, static_cast<unsigned long long>(n));
             }
             RR_SEC_MARK(cnt, this_pc < 4u ? 2 : 3);
-            park_settle(pa, s, m, slot, in, this_pc, act, sc.lean == 0u, true);
+            guest = guest && moved;  // (nothing to bring up to date in the slot of a guest that took no step)
+            park_settle(pa, s, m, slot, local || guest, this_pc, act, sc.lean == 0u, true, GUESTS, guest);
             RR_SEC_MARK(cnt, 4);
         } else if (code == OP_SUBTREE) {
 #ifdef RR_ABLATE_SUBTREE  // timing-only build: wrong images, prices the BVH part of a bounce

@@ -1032,6 +1032,9 @@ PathsChoice choose_paths_kernel(const rr_context* ctx, int count) {
         if (ctx->has_general_subtrees) return w5 ? RR_PK(COUNT_OFF, true, true, true, true, W5, true) : RR_PK(COUNT_OFF, true, true, true, true);
         // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
         // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
+        // (two or more subtrees: the builds in which parked lanes are guests of the other subtrees' visits)
+        if (ctx->info.subtree_ops[0] >= 2u)
+            return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false, true);
         return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false);
     }
     if (ctx->prog_vector_ops) {

@@ -170,7 +170,10 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 }
 
 #ifndef RR_WF_FINISH_PARK_BELOW
-#define RR_WF_FINISH_PARK_BELOW 20  // lanes still descending in a subtree are parked once fewer than this many are left
+#define RR_WF_FINISH_PARK_BELOW 20  // k_wf_finish: lanes still descending in a subtree are parked once fewer than this many are left
+#endif
+#ifndef RR_PATHS_PARK_BELOW
+#define RR_PATHS_PARK_BELOW 12  // k_wf_paths: the same (20 until dead paths ended where they die: with the rays that are left, 12 is +1 % on final_scene and the random spheres, +0.3 % on Suzanne; the mesh's k_wf_finish is 12 % slower with it and keeps 20)
 #endif
 #ifndef RR_WF_FINISH_PARK_MIN_STEPS
 #define RR_WF_FINISH_PARK_MIN_STEPS 6  // machine steps a visit of a subtree takes at least, so that parked lanes get on
@@ -197,7 +200,10 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
 // -4 % Cornell box).  The host picks 5 for lean scenes and for scenes whose subtrees are all simple.
 // LEAN: a build for lean scenes (rr_context::lean_scene) without the code they do not need; with WAVES above the default it
 // is for lean scenes without triangles and has no triangle code either.
-template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD, bool LEAN = false>
+// GUESTS: a build for scenes with two or more subtrees, all simple: lanes parked at one subtree take the steps of the visits of
+// the others (traverse_parking).
+template <int COUNT, bool VEC, bool PARK = false, bool GENERAL = true, bool REF_SEM = false, int WAVES = RR_RENDER_WAVES_PER_SIMD, bool LEAN = false,
+          bool GUESTS = false>
 __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs a, float4* __restrict__ values,
                                                                               unsigned int* next_path, unsigned long long* counters) {
     // REF_SEM: a build that is only launched for scenes with the reference's own semantics, so that the switch is a constant
@@ -281,8 +287,8 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             g.n = draws;
             if (g.n & 3u) g.refill();
             const uint32_t n_fresh = static_cast<uint32_t>(__popcll(RR_BALLOT(run && !was_parked)));
-            const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_WF_FINISH_PARK_BELOW : 0u;
-            traverse_parking<COUNT, GENERAL>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
+            const uint32_t park_below = (n_fresh >= RR_WF_FINISH_PARK_MIN_FRESH || !exhausted) ? RR_PATHS_PARK_BELOW : 0u;
+            traverse_parking<COUNT, GENERAL, GUESTS && !GENERAL>(sc, ro, rd, time, 0.001f, kF32Max, run, park, pa, g, stk, stride, park_below, RR_WF_FINISH_PARK_MIN_STEPS, RR_PATHS_LEAF_WAIT, cnt, t, ref);
             draws = g.n;
             parked = run && park != NONE;
         } else {
