@@ -212,6 +212,7 @@ def parse_args(argv=None):
     ap.add_argument("--trace-dead-paths", action="store_true",
                     help="RR_FLAG_TRACE_DEAD_PATHS: walk paths on after their throughput has become exactly zero, as the reference does "
                          "(the default ends them there: same samples unless the rest of the walk meets a NaN)")
+    ap.add_argument("--no-full-walk", action="store_true", help="skip the second figure (one step with RR_FLAG_TRACE_DEAD_PATHS)")
     ap.add_argument("--specialize", default="auto", choices=["auto", "always", "off"],
                     help="rr_scene_specialize after the upload (outside the timed region, like the upload): auto = only programs without BVH subtrees")
     ap.add_argument("--launch-check", action="store_true",
@@ -416,9 +417,11 @@ def run_ranks(args, world, rank):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, partition):
+    def measure(scaling, partition, extra_flags=0, steps=None, warmup=None):
         """W untimed and K timed steps of one job shared by the ranks -> dict of what rank 0 reports."""
-        job = multi.job_params(W, H, spp, K, depth, args.seed, world, scaling, flags=args.flags)
+        n_steps = args.steps if steps is None else steps
+        n_warm = args.warmup if warmup is None else warmup
+        job = multi.job_params(W, H, spp, K, depth, args.seed, world, scaling, flags=args.flags | extra_flags)
         p = multi.rank_share(job, rank, world, partition)
         comb = multi.Combiner(dist, world, partition, H, stage_through_host=rehearsal)
         n_sl, rows = p.slice_end - p.slice_begin, p.rows
@@ -437,16 +440,16 @@ def run_ranks(args, world, rank):
             if rank == 0:
                 ctx.cast_u8_device(whole[0].data_ptr(), rgb8.data_ptr(), whole[0].numel(), stream)
 
-        for _ in range(args.warmup):
+        for _ in range(n_warm):
             step()
         barrier()
         counters.zero_()
         torch.cuda.synchronize()
         # HIP events on the stream the kernels are launched on (torch's current stream is the one handed to the library;
         # what the library runs on its second stream is ordered inside the bracket by its own events)
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n_steps):
             step(events[i])
         barrier()
         elapsed = time.perf_counter() - t0
@@ -472,11 +475,16 @@ def run_ranks(args, world, rank):
             image = {"sha256": hashlib.sha256(img.tobytes()).hexdigest(), "mean_rgb": [round(float(x), 4) for x in img.reshape(-1, 3).mean(axis=0)]}
         spt = job.samples_per_pixel // job.n_slices
         samples_per_step = W * H * spt * job.n_slices
-        assert int(counts_all[0]) == samples_per_step * args.steps, (int(counts_all[0]), samples_per_step, args.steps)
+        assert int(counts_all[0]) == samples_per_step * n_steps, (int(counts_all[0]), samples_per_step, n_steps)
         return dict(job=job, comb=comb, elapsed=elapsed, kernel_ms=kernel_ms, per_rank_ms=per_rank_ms, counts_all=counts_all,
-                    counts_rank=counters.cpu().numpy(), value=int(counts_all[0]) / elapsed / 1e6, image=image)
+                    counts_rank=counters.cpu().numpy(), value=int(counts_all[0]) / elapsed / 1e6, image=image, steps=n_steps)
 
     m = measure(scaling, partition)
+    # a second figure beside the headline: the same job with every dead path walked to its end, which is the work the reference
+    # does (RR_FLAG_TRACE_DEAD_PATHS); one step, the kernels are warm
+    full_walk = None
+    if world == 1 and not (args.flags & abi.FLAG_TRACE_DEAD_PATHS) and not args.no_full_walk:
+        full_walk = measure(scaling, partition, extra_flags=abi.FLAG_TRACE_DEAD_PATHS, steps=1, warmup=0)
     weak = None
     if world > 1 and args.scaling is None and not args.no_weak:
         weak = measure("weak", "slices")
@@ -595,6 +603,15 @@ def run_ranks(args, world, rank):
             "roofline": roofline,
             "reference_published": {"msamples_per_s": 0.67, "source": "src/notes.txt:1-5 (Cornell box 600x600, 200 spp, depth 200, unknown CPU)"},
         }
+        if full_walk:
+            fc = full_walk["counts_all"]
+            out["full_walk"] = {"value": round(full_walk["value"], 3), "unit": "Msamples/s", "steps": 1,
+                                "ms_per_step": round(full_walk["elapsed"] * 1e3, 3),
+                                "mrays_per_s": round(int(fc[1]) / full_walk["elapsed"] / 1e6, 3),
+                                "rays_per_sample": round(int(fc[1]) / max(1, int(fc[0])), 4),
+                                "note": "the same job with RR_FLAG_TRACE_DEAD_PATHS: every path is walked to its end after its throughput has become "
+                                        "exactly zero, as the reference does (render.rs:29-34); `value` above is the library's default, which ends such "
+                                        "paths (same samples unless the rest of the walk meets a NaN: tests/test_dead_paths.py)"}
         if weak:
             wj = weak["job"]
             out["weak"] = {"value": round(weak["value"], 3), "unit": "Msamples/s", "ms_per_step": round(weak["elapsed"] / args.steps * 1e3, 3),

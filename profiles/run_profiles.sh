@@ -19,13 +19,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$SPP" --steps 3 --warmup 1 --no-cpu --no-count > "$OUT/bench_under_trace.json" 2> "$OUT/bench_under_trace.err" || { echo "trace pass failed"; exit 1; }
+    python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$SPP" --steps 3 --warmup 1 --no-cpu --no-count --no-full-walk > "$OUT/bench_under_trace.json" 2> "$OUT/bench_under_trace.err" || { echo "trace pass failed"; exit 1; }
 echo "trace ok"
 
 pass() {
     name=$1; shift
     timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
-        python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$PMC_SPP" --steps 1 --warmup 0 --no-cpu --no-count > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || { echo "pmc pass $name failed"; exit 1; }
+        python3 "$ROOT/bench.py" --workload "$WORKLOAD" --spp "$PMC_SPP" --steps 1 --warmup 0 --no-cpu --no-count --no-full-walk > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || { echo "pmc pass $name failed"; exit 1; }
     echo "pass $name ok"
 }
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_BRANCH &&
