@@ -67,6 +67,11 @@ int main(int argc, char** argv) {
     rr_context* ctx = NULL;
     if (rr_context_create(0, &ctx) != RR_OK) return fail_dev("rr_context_create");
     if (rr_scene_upload(ctx, &flat) != RR_OK) return fail_dev("rr_scene_upload");
+    /* Optional: a kernel compiled for this scene's program where that pays (programs without BVH subtrees).  Same image;
+     * without a runtime compiler on the host the interpreter renders, so a failure here is only reported. */
+    if (rr_scene_specialize(ctx, RR_SPECIALIZE_AUTO) != RR_OK) fprintf(stderr, "render_scene: %s (rendering with the interpreter)\n", rr_last_error());
+    rr_scene_info info;
+    if (rr_scene_info_get(ctx, &info) != RR_OK) return fail_dev("rr_scene_info_get");
     size_t n = (size_t)p.width * p.height * 3u;
     uint8_t* rgb = (uint8_t*)malloc(n);
     if (!rgb) {
@@ -88,8 +93,9 @@ int main(int argc, char** argv) {
         perror(out_path);
         return 2;
     }
-    fprintf(stderr, "render_scene: %s %ux%u, %llu samples, %llu rays, %.3f ms on the GPU\n", scene, p.width, p.height,
-            (unsigned long long)counters.samples, (unsigned long long)counters.rays, ms);
+    fprintf(stderr, "render_scene: %s %ux%u, %llu samples, %llu rays, %.3f ms on the GPU%s\n", scene, p.width, p.height,
+            (unsigned long long)counters.samples, (unsigned long long)counters.rays, ms,
+            info.specialized ? " (kernel compiled for this scene's program)" : "");
     free(rgb);
     rr_context_destroy(ctx);
     rrh_builder_free(b);

@@ -55,3 +55,6 @@ def test_example_image_equals_ctypes_path(gpu_ctx, tmp_path, scene, W, H, spp, d
     assert got.shape == (H, W, 3)
     assert np.array_equal(got, res["rgb8"])
     assert got.max() > 0
+    # (the example asks for RR_SPECIALIZE_AUTO: the Cornell box, a program without BVH subtrees, was rendered by the kernel
+    # compiled for it; the ctypes render above by the interpreter)
+    assert ("compiled for this scene's program" in r.stderr) == (scene == "cornell_box"), r.stderr
