@@ -295,13 +295,17 @@ typedef struct rr_render_params {
  * pdf is 0 (material.rs:170-175), or a Lambertian hit whose sampled direction points below the surface (material.rs:111-114) --
  * everything it meets later is multiplied by zero.  The reference follows the path to its end all the same (render.rs:29-34)
  * and adds its 0; by default the kernels end it there and add the 0 at once (final_scene: 57 % of all rays are such, most of
- * them scattering on in the fog; 2.35 x the throughput).  The sample differs only where the rest of the walk would have met a
+ * them scattering on in the fog; 2.5 x the throughput).  The sample differs only where the rest of the walk would have met a
  * NaN or an infinity (0 * NaN = NaN: the 0/0 of render.rs:34 where a surface's mixture pdf is 0), which the reference turns into
  * one zeroed pixel of one slice (render.rs:102-119); with a light the library can sample that is a few samples in 10^8
  * (tests/test_dead_paths.py).  This flag makes the kernels walk dead paths to their end exactly as the reference
  * does.  The CPU oracle honours the same flag.  A throughput that is NaN in every channel ends a path as well, and that is
  * exact: NaN times whatever follows is NaN, which is what the ended path leaves as its sample.                              */
 #define RR_FLAG_TRACE_DEAD_PATHS 128u
+/* The path-granular kernel hands the pixels of a scene with BVH subtrees to its lanes in 8x8 tiles (a wave's camera rays then
+ * walk the same part of the BVHs); this flag keeps it to 64 pixels of a row per wave, the order it uses for scenes without
+ * subtrees (for measurements and tests: the order changes no result).                                                        */
+#define RR_FLAG_ROW_ORDER 256u
 
 typedef struct rr_counters {
     uint64_t samples;     /* camera rays started                                         */

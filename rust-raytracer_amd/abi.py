@@ -26,6 +26,7 @@ FLAG_PATHS = 16
 FLAG_COUNT_PRODUCTION = 32
 FLAG_NARROW_NODES = 64
 FLAG_TRACE_DEAD_PATHS = 128
+FLAG_ROW_ORDER = 256
 N_COUNTERS = 10  # u64 words of rr_counters
 PERLIN_POINTS = 256
 NOALLOC_MAX_PATHS = 4194304

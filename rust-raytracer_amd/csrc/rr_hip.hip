@@ -1902,6 +1902,8 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.pass_slices = here;
             w.strip_pixels = 0;
+            // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix)
+            w.tile_paths = (!wavefront && ctx->has_subtrees && !(p->flags & RR_FLAG_ROW_ORDER)) ? 1u : 0u;
             if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
                 w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
             w.slice_first = p->slice_begin + s0;

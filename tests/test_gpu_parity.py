@@ -1160,6 +1160,30 @@ def test_odd_image_sizes(gpu_ctx, W, H):
     assert_render_parity(got, want, min_close=0.95, mean_tol=0.05)
 
 
+@pytest.mark.parametrize("W,H", [(2, 2), (7, 3), (8, 8), (9, 8), (8, 9), (37, 21), (65, 9), (16, 24), (100, 41)])
+def test_tile_order_of_the_path_kernel_changes_no_bit(gpu_ctx, W, H):
+    """On scenes with BVH subtrees the path kernel hands out pixels in 8x8 tiles (then the columns and the rows that tiles do not
+    cover): the same bits as the row order (RR_FLAG_ROW_ORDER) and as the item-granular kernel, for image sizes with and
+    without remainders, for bands of rows that start and end anywhere, slice ranges and sample offsets; and the entry point
+    that allocates nothing takes the same order."""
+    b, flat, _ = config_scene("final")
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=4, max_depth=12, seed=21)
+    base = gpu_ctx.render(device.make_params(W, H, 8, **kw))
+    for flags in (abi.FLAG_ROW_ORDER, abi.FLAG_PERSISTENT, abi.FLAG_PATHS, abi.FLAG_PATHS | abi.FLAG_ROW_ORDER | abi.FLAG_COUNTERS):
+        other = gpu_ctx.render(device.make_params(W, H, 8, flags=flags, **kw))
+        assert np.array_equal(base["slice_sums"], other["slice_sums"], equal_nan=True), flags
+        assert np.array_equal(base["rgb8"], other["rgb8"])
+    if H >= 9:
+        r0, r1 = 3, H - 2
+        band = gpu_ctx.render(device.make_params(W, H, 8, row_begin=r0, row_end=r1, slice_begin=1, slice_end=3, sample_offset=7, **kw))
+        rows = gpu_ctx.render(device.make_params(W, H, 8, row_begin=r0, row_end=r1, slice_begin=1, slice_end=3, sample_offset=7,
+                                                 flags=abi.FLAG_ROW_ORDER, **kw))
+        assert np.array_equal(band["slice_sums"], rows["slice_sums"], equal_nan=True)
+        whole = gpu_ctx.render(device.make_params(W, H, 8, sample_offset=7, **kw))
+        assert np.array_equal(band["slice_sums"], whole["slice_sums"][1:3, r0:r1], equal_nan=True)
+
+
 def test_degenerate_parameters(gpu_ctx):
     b, flat, _ = config_scene("cornell")
     gpu_ctx.upload(flat)
