@@ -1906,6 +1906,7 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
             w.tile_paths = (!wavefront && ctx->has_subtrees && !(p->flags & RR_FLAG_ROW_ORDER)) ? 1u : 0u;
             if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
                 w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
+            w.claim_max = ctx->auto_pipeline ? RR_WF_CLAIM_LARGE_SCENE : RR_WF_CLAIM_SMALL_SCENE;
             w.slice_first = p->slice_begin + s0;
             w.slice_out = s0;
             int rc;

@@ -40,7 +40,7 @@ constexpr uint32_t WF_STAGE = 1024;  // queue entries a shading wave collects be
 // A wave fetches new rays once this many of its lanes have none.  Measured on the triangle-mesh and the
 // final scene: 8: -10 %, 16: 0, 32: +12 %, 40-48: +13 %, 64 (never refill a running wave): +3 %.  A refill
 // stalls the lanes still traversing for two dependent loads and three divisions, so it has to fill many.
-#define RR_WF_REFILL_IDLE 16
+#define RR_WF_REFILL_IDLE 64
 #endif
 
 struct WfState {     // one entry per path in each array
@@ -50,8 +50,19 @@ struct WfState {     // one entry per path in each array
                      // its sample value once it has ended
     uint4* hit;      // (t, primitive ref, material, owner word) of the closest hit, ref NONE for a miss
 };
+// Queue entries a traversal wave claims at a time, at most (WfArgs::claim_max; at least 64).  A scene that the dies' L2s do
+// not hold: 64, one wave's worth — the waves of a die then walk neighbouring cells of the image at the same time, and what
+// they fetch of the scene is one small region (1.1 M-primitive mesh: 256 -> 64 entries +10 %, 4096 -> 64 +22 % with rows
+// for cells).  A cache-resident scene, whose rays are short: 512, or the claims' atomics take as long as the rays (64
+// entries halve Suzanne and final_scene).
+#ifndef RR_WF_CLAIM_LARGE_SCENE
+#define RR_WF_CLAIM_LARGE_SCENE 64u
+#endif
+#ifndef RR_WF_CLAIM_SMALL_SCENE
+#define RR_WF_CLAIM_SMALL_SCENE 512u
+#endif
 #ifndef RR_WF_STRIP_ROWS
-#define RR_WF_STRIP_ROWS 4u  // image rows per strip of the wavefront pipeline's path numbering (0: sample-major numbering)
+#define RR_WF_STRIP_ROWS 8u  // image rows per strip of the wavefront pipeline's path numbering (0: sample-major numbering)
 #endif
 constexpr uint32_t WF_XCDS = 8;  // accelerator dies of an MI355X, each with an L2 of its own
 struct WfCtl {
@@ -77,6 +88,7 @@ struct WfArgs {
     uint32_t pass_slices;  // n_slots / n_pixels: slices in this pass
     uint32_t n_sub;        // (samples in this batch) * pass_slices: the paths of one pixel in this batch
     uint32_t trace_dead;   // RR_FLAG_TRACE_DEAD_PATHS: paths go on after their throughput has become zero (see dead_path)
+    uint32_t claim_max;    // k_wf_traverse: queue entries a wave claims at a time, at most (RR_WF_CLAIM_*)
     uint32_t tile_paths;   // k_wf_paths: the pixels of the band are numbered in 8x8 tiles (wf_tile_to_pix) instead of row by row
     uint64_t seed;
 };
@@ -93,6 +105,52 @@ struct WfPathPos {
     uint32_t pix;  // pixel within the band of rows
     uint32_t sub;  // s_local * pass_slices + slice_local
 };
+#ifndef RR_WF_CELL_W
+#define RR_WF_CELL_W 2u
+#endif
+#ifndef RR_WF_CELL_H
+#define RR_WF_CELL_H 2u
+#endif
+#ifndef RR_WF_CELL_MAJOR
+#define RR_WF_CELL_MAJOR 1
+#endif
+// Inside a full strip (RR_WF_STRIP_ROWS rows of the image) the pixels are numbered cell by cell.
+__device__ __forceinline__ WfPathPos wf_strip_pos(const WfArgs& a, uint32_t idx) {  // position within the strip's paths -> (pixel within the strip, sub)
+    constexpr uint32_t CW = RR_WF_CELL_W, CH = RR_WF_CELL_H, CP = CW * CH, ROWS = RR_WF_STRIP_ROWS, CY = ROWS / CH;
+    const uint32_t wc = a.width - a.width % CW;
+#if RR_WF_CELL_MAJOR
+    const uint32_t cell_part = ROWS * wc * a.n_sub;
+    if (idx < cell_part) {
+        const uint32_t per_cell = CP * a.n_sub, c = idx / per_cell, rem = idx - c * per_cell, sub = rem / CP, in = rem % CP;
+        const uint32_t cx = c / CY, cy = c % CY;
+        return WfPathPos{(cy * CH + in / CW) * a.width + cx * CW + in % CW, sub};
+    }
+    const uint32_t q = idx - cell_part, right = a.width - wc, per = ROWS * right, sub = q / per, r = q - sub * per, y = r / right;
+    return WfPathPos{y * a.width + wc + (r - y * right), sub};
+#else
+    const uint32_t len = ROWS * a.width, sub = idx / len, r = idx - sub * len;
+    if (r < ROWS * wc) {
+        const uint32_t c = r / CP, in = r % CP, cx = c / CY, cy = c % CY;
+        return WfPathPos{(cy * CH + in / CW) * a.width + cx * CW + in % CW, sub};
+    }
+    const uint32_t q = r - ROWS * wc, right = a.width - wc, y = q / right;
+    return WfPathPos{y * a.width + wc + (q - y * right), sub};
+#endif
+}
+__device__ __forceinline__ uint32_t wf_strip_index(const WfArgs& a, uint32_t r, uint32_t sub) {  // the inverse: pixel r of the strip, sub -> position
+    constexpr uint32_t CW = RR_WF_CELL_W, CH = RR_WF_CELL_H, CP = CW * CH, ROWS = RR_WF_STRIP_ROWS, CY = ROWS / CH;
+    const uint32_t wc = a.width - a.width % CW;
+    const uint32_t y = r / a.width, x = r - y * a.width;
+#if RR_WF_CELL_MAJOR
+    if (x < wc) return ((x / CW) * CY + y / CH) * (CP * a.n_sub) + sub * CP + (y % CH) * CW + x % CW;
+    const uint32_t right = a.width - wc;
+    return ROWS * wc * a.n_sub + sub * (ROWS * right) + y * right + (x - wc);
+#else
+    const uint32_t len = ROWS * a.width;
+    if (x < wc) return sub * len + ((x / CW) * CY + y / CH) * CP + (y % CH) * CW + x % CW;
+    return sub * len + ROWS * wc + y * (a.width - wc) + (x - wc);
+#endif
+}
 template <bool STRIPS = true>
 __device__ __forceinline__ WfPathPos wf_path_pos(const WfArgs& a, uint32_t p) {
     if (!STRIPS || a.strip_pixels == 0u) {
@@ -103,6 +161,10 @@ __device__ __forceinline__ WfPathPos wf_path_pos(const WfArgs& a, uint32_t p) {
     const uint32_t strip = p / per_strip, rem = p - strip * per_strip;
     const uint32_t first = strip * a.strip_pixels;
     const uint32_t len = min(a.strip_pixels, a.n_pixels - first);  // (the last strip may be shorter)
+    if (len == RR_WF_STRIP_ROWS * a.width) {  // a full strip: its pixels go cell by cell (wf_strip_pos_to_pix)
+        const WfPathPos q = wf_strip_pos(a, rem);
+        return WfPathPos{first + q.pix, q.sub};
+    }
     const uint32_t sub = rem / len;
     return WfPathPos{first + (rem - sub * len), sub};
 }
@@ -112,6 +174,7 @@ __device__ __forceinline__ uint32_t wf_path_index(const WfArgs& a, uint32_t pix,
         return (sub / a.pass_slices) * a.n_slots + (sub % a.pass_slices) * a.n_pixels + (a.tile_paths ? wf_pix_to_tile(a, pix) : pix);
     const uint32_t strip = pix / a.strip_pixels, first = strip * a.strip_pixels;
     const uint32_t len = min(a.strip_pixels, a.n_pixels - first);
+    if (len == RR_WF_STRIP_ROWS * a.width) return first * a.n_sub + wf_strip_index(a, pix - first, sub);
     return first * a.n_sub + sub * len + (pix - first);
 }
 // (pixel, per-pixel sample number) of a path: the key of its random streams.  The pixel is its position in the whole
@@ -437,7 +500,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                 uint32_t base = 0, chunk = 0;
                 if ((threadIdx.x & 63u) == 0) {
                     const uint32_t seen = min(__hip_atomic_load(&ctl->xcur[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi - lo);
-                    chunk = min(max((hi - lo - seen) / (n_waves / WF_XCDS * 2u + 1u), 64u), 4096u);
+                    chunk = min(max((hi - lo - seen) / (n_waves / WF_XCDS * 2u + 1u), 64u), a.claim_max);
                     base = atomicAdd(&ctl->xcur[part], chunk);
                 }
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -465,7 +528,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
                     active = true;
                 }
             }
-        }
+    }
         if (!RR_ANY(active)) {
             if (exhausted) break;
             continue;

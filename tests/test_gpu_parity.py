@@ -1184,6 +1184,28 @@ def test_tile_order_of_the_path_kernel_changes_no_bit(gpu_ctx, W, H):
         assert np.array_equal(band["slice_sums"], whole["slice_sums"][1:3, r0:r1], equal_nan=True)
 
 
+@pytest.mark.parametrize("W,H,spp,slices", [(64, 64, 8, 4), (61, 37, 8, 4), (7, 50, 6, 2), (33, 8, 12, 4), (130, 17, 3, 3), (2, 16, 8, 8), (96, 80, 1, 1),
+                                            (1, 9, 16, 4)])
+def test_cell_order_of_the_pipeline_changes_no_bit(gpu_ctx, W, H, spp, slices):
+    """The wavefront pipeline numbers its paths strip by strip (8 image rows) and, inside a full strip, cell by cell: all
+    samples of a 2x2 cell of pixels before the next cell's, so that a traversal wave's 64 rays leave through a few
+    neighbouring pixels; columns that cells do not cover and a last strip of fewer rows follow in row order.  Whatever the
+    sizes, bands and slice ranges: the path kernel's bits."""
+    b, flat, _ = config_scene("suzanne")
+    gpu_ctx.upload(flat)
+    kw = dict(n_slices=slices, max_depth=10, seed=33)
+    want = gpu_ctx.render(device.make_params(W, H, spp, flags=abi.FLAG_PATHS | abi.FLAG_ROW_ORDER, **kw))
+    got = gpu_ctx.render(device.make_params(W, H, spp, flags=abi.FLAG_WAVEFRONT, **kw))
+    assert np.array_equal(want["slice_sums"], got["slice_sums"], equal_nan=True)
+    assert np.array_equal(want["rgb8"], got["rgb8"])
+    assert want["counters"]["rays"] == got["counters"]["rays"] and want["counters"]["samples"] == got["counters"]["samples"]
+    if H >= 9 and slices >= 3:
+        band = dict(row_begin=2, row_end=H - 3, slice_begin=1, slice_end=slices - 1, sample_offset=5)
+        want = gpu_ctx.render(device.make_params(W, H, spp, flags=abi.FLAG_PATHS | abi.FLAG_ROW_ORDER, **band, **kw))
+        got = gpu_ctx.render(device.make_params(W, H, spp, flags=abi.FLAG_WAVEFRONT, **band, **kw))
+        assert np.array_equal(want["slice_sums"], got["slice_sums"], equal_nan=True)
+
+
 def test_degenerate_parameters(gpu_ctx):
     b, flat, _ = config_scene("cornell")
     gpu_ctx.upload(flat)
