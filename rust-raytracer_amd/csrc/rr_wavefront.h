@@ -37,9 +37,11 @@ constexpr uint32_t WF_STAGE = 1024;  // queue entries a shading wave collects be
 #define RR_WF_LEAF_LANES 24  // lanes waiting at a leaf that make the wave take the leaf move at once
 #endif
 #ifndef RR_WF_REFILL_IDLE
-// A wave fetches new rays once this many of its lanes have none.  Measured on the triangle-mesh and the
-// final scene: 8: -10 %, 16: 0, 32: +12 %, 40-48: +13 %, 64 (never refill a running wave): +3 %.  A refill
-// stalls the lanes still traversing for two dependent loads and three divisions, so it has to fill many.
+// A wave fetches new rays once this many of its lanes have none: 64, a whole cohort at a time.  The 64 entries of a claim
+// are the samples of a 2x2 cell of pixels (wf_strip_pos), rays that meet the same nodes and leaves in the same steps, so
+// that most lanes take each move of the machine together; rays of another cell fed to the lanes that fall idle are at
+// other kinds of records in every step and the wave executes both moves for a part of its lanes each (1.1 M-primitive
+// mesh, Msamples/s: 16 idle lanes 80.6, 24: 75.8, 32: 74.0, 40-56: 65.6-68.3, 64: 94.8).
 #define RR_WF_REFILL_IDLE 64
 #endif
 
@@ -95,8 +97,8 @@ struct WfArgs {
 
 // How the paths of a batch are numbered.  The persistent kernel k_wf_paths numbers them sample-major: path p is sample
 // s0 + p / n_slots of slot p % n_slots, slot = slice * n_pixels + pixel.  The wavefront pipeline (scenes larger than the
-// L2s) numbers them strip by strip (a.strip_pixels != 0): a strip is a few image rows, and all of a strip's paths — every
-// slice and batch sample of its pixels — come before the next strip's, pixel fastest.  Rays that are neighbours in the queue
+// L2s) numbers them strip by strip (a.strip_pixels != 0): a strip is eight image rows, and all of a strip's paths — every
+// slice and batch sample of its pixels — come before the next strip's, cell by cell (wf_strip_pos).  Rays that are neighbours in the queue
 // are then neighbours in the image whatever their sample number, and a contiguous range of the queue is a band of the image:
 // that is what lets each die keep its part of the scene in its own L2 (k_wf_traverse).  The numbering changes no result:
 // every random stream is keyed by (pixel, sample), and k_wf_accumulate adds a pixel's samples in sample order either way.
@@ -111,14 +113,15 @@ struct WfPathPos {
 #ifndef RR_WF_CELL_H
 #define RR_WF_CELL_H 2u
 #endif
-#ifndef RR_WF_CELL_MAJOR
-#define RR_WF_CELL_MAJOR 1
-#endif
-// Inside a full strip (RR_WF_STRIP_ROWS rows of the image) the pixels are numbered cell by cell.
+// Inside a full strip (RR_WF_STRIP_ROWS rows of the image) the paths are numbered cell by cell: all of the batch's paths of
+// a cell of RR_WF_CELL_W x RR_WF_CELL_H pixels — every slice and sample, pixel fastest — before the next cell's, the cells
+// column by column; then the columns that cells do not cover, sample-major.  64 consecutive paths, what a traversal wave
+// takes at a time, are then 16 samples of one cell (or all samples of several cells), camera rays that differ by a pixel.
+// Measured on the 1.1 M-primitive mesh at 8 samples per pixel, Msamples/s: rows 73.3; 8x8 cells one sample each 90.1;
+// cell-major 8x8 90.6, 8x4 92.0, 4x4 94.6, 4x2 95.4, 2x2 95.3.  A strip of fewer rows (the band's last) keeps the row order.
 __device__ __forceinline__ WfPathPos wf_strip_pos(const WfArgs& a, uint32_t idx) {  // position within the strip's paths -> (pixel within the strip, sub)
     constexpr uint32_t CW = RR_WF_CELL_W, CH = RR_WF_CELL_H, CP = CW * CH, ROWS = RR_WF_STRIP_ROWS, CY = ROWS / CH;
     const uint32_t wc = a.width - a.width % CW;
-#if RR_WF_CELL_MAJOR
     const uint32_t cell_part = ROWS * wc * a.n_sub;
     if (idx < cell_part) {
         const uint32_t per_cell = CP * a.n_sub, c = idx / per_cell, rem = idx - c * per_cell, sub = rem / CP, in = rem % CP;
@@ -127,29 +130,14 @@ __device__ __forceinline__ WfPathPos wf_strip_pos(const WfArgs& a, uint32_t idx)
     }
     const uint32_t q = idx - cell_part, right = a.width - wc, per = ROWS * right, sub = q / per, r = q - sub * per, y = r / right;
     return WfPathPos{y * a.width + wc + (r - y * right), sub};
-#else
-    const uint32_t len = ROWS * a.width, sub = idx / len, r = idx - sub * len;
-    if (r < ROWS * wc) {
-        const uint32_t c = r / CP, in = r % CP, cx = c / CY, cy = c % CY;
-        return WfPathPos{(cy * CH + in / CW) * a.width + cx * CW + in % CW, sub};
-    }
-    const uint32_t q = r - ROWS * wc, right = a.width - wc, y = q / right;
-    return WfPathPos{y * a.width + wc + (q - y * right), sub};
-#endif
 }
 __device__ __forceinline__ uint32_t wf_strip_index(const WfArgs& a, uint32_t r, uint32_t sub) {  // the inverse: pixel r of the strip, sub -> position
     constexpr uint32_t CW = RR_WF_CELL_W, CH = RR_WF_CELL_H, CP = CW * CH, ROWS = RR_WF_STRIP_ROWS, CY = ROWS / CH;
     const uint32_t wc = a.width - a.width % CW;
     const uint32_t y = r / a.width, x = r - y * a.width;
-#if RR_WF_CELL_MAJOR
     if (x < wc) return ((x / CW) * CY + y / CH) * (CP * a.n_sub) + sub * CP + (y % CH) * CW + x % CW;
     const uint32_t right = a.width - wc;
     return ROWS * wc * a.n_sub + sub * (ROWS * right) + y * right + (x - wc);
-#else
-    const uint32_t len = ROWS * a.width;
-    if (x < wc) return sub * len + ((x / CW) * CY + y / CH) * CP + (y % CH) * CW + x % CW;
-    return sub * len + ROWS * wc + y * (a.width - wc) + (x - wc);
-#endif
 }
 template <bool STRIPS = true>
 __device__ __forceinline__ WfPathPos wf_path_pos(const WfArgs& a, uint32_t p) {
@@ -485,7 +473,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     // The queue is cut into one contiguous part per die (XCD): a wave claims from the part of the die it runs on and, once that
     // is used up, from the next die's.  Neighbours in the queue are neighbours in the image (wf_path_key), so a die's rays walk
     // the same region of the scene and its L2 (4 MB, not shared between dies) serves more of their fetches than when every die
-    // sees every region.  A claim is a fraction of what is left of the part (at least 64 entries, at most 4096), so the claims
+    // sees every region.  A claim is a fraction of what is left of the part (at least 64 entries, at most WfArgs::claim_max), so the claims
     // shrink towards the end and the waves finish together whatever the rays of the last entries cost.
     const uint32_t xcd = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & (WF_XCDS - 1u);  // HW_REG_XCC_ID, bits 3..0
     uint32_t part = xcd, parts_tried = 0;
