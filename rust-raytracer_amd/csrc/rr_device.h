@@ -844,7 +844,10 @@ __device__ __forceinline__ void trav_pop_simple(const DevScene& sc, Trav& m, uin
     }
 }
 
-template <int COUNT, class World>
+// PLAIN (trav_leaf, trav_pop): a build for scenes without moving spheres, instances and media (rr_scene_upload knows), which
+// leaves their moves out: fewer instructions in every move and, in k_wf_traverse, a fifth fewer scalar registers moved to
+// and from vector lanes around them (1.1 M-primitive mesh: +5.4 %).
+template <int COUNT, class World, bool PLAIN = false>
 __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const World& world, uint32_t* stk, uint32_t stride, Counts& cnt) {
     // ------------------------------------------------ primitive, list, instance or medium
     if (m.node != NONE && dtag(m.node) != RR_TAG_BVH) {
@@ -858,8 +861,8 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
         if (tag == RR_TAG_SPHERE) rp = sc.sphere, roff = idx;
         if (tag == RR_TAG_RECT) rp = sc.rect, roff = 2 * idx;
         if (tag == RR_TAG_CUBOID) rp = sc.cuboid, roff = 2 * idx;
-        if (tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere;
-        if (tag == RR_TAG_LIST || tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM) roff = 0;
+        if (!PLAIN && tag == RR_TAG_MOVING_SPHERE) rp = sc.msphere;
+        if (tag == RR_TAG_LIST || (!PLAIN && (tag == RR_TAG_INSTANCE || tag == RR_TAG_MEDIUM))) roff = 0;
         const float4 q0 = rp[roff], q1 = rp[roff + 1], q2 = rp[roff + 2];
         records_arrived(q0, q1, q2);
         m.node = NONE;
@@ -916,7 +919,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
                     }
                 }
             }
-        } else if (tag == RR_TAG_MOVING_SPHERE) {
+        } else if (!PLAIN && tag == RR_TAG_MOVING_SPHERE) {
             if (COUNT) cnt.sphere_tests++;
             float t;
             if (test_sphere(msphere_center(q0, q1, world.time()), q2.x, m.o, m.d, m.tmin, m.tmax, t)) {
@@ -932,7 +935,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
                 m.sp += 2;
                 m.node = sc.child_refs[l.x];
             }
-        } else if (tag == RR_TAG_INSTANCE) {
+        } else if (!PLAIN && tag == RR_TAG_INSTANCE) {
             if (COUNT) cnt.inst_visits++;
             stk[m.sp * stride] = frame_word(FK_INST, idx);
             m.sp += 1;
@@ -940,7 +943,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
             inst_apply_ray(sc.inst[2 * idx], o, d);
             m.set_ray(o, d);
             m.node = __float_as_uint(sc.inst[2 * idx + 1].x);
-        } else {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
+        } else if (!PLAIN) {  // RR_TAG_MEDIUM: first boundary probe over (f32::MIN, f32::MAX), collider.rs:437
             if (COUNT) cnt.inst_visits++;
             stk[m.sp * stride] = __float_as_uint(m.tmin);
             stk[(m.sp + 1) * stride] = __float_as_uint(m.tmax);
@@ -956,7 +959,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& m, const Wor
     }
 }
 
-template <int COUNT, class World, class Draw, bool WIDE = false>
+template <int COUNT, class World, class Draw, bool WIDE = false, bool PLAIN = false>
 __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const World& world, Draw& draw, uint32_t* stk, uint32_t stride,
                                          Counts& cnt) {
     // ------------------------------------------- return to the callers
@@ -993,14 +996,14 @@ __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const Worl
             } else {
                 m.sp -= 2;
             }
-        } else if (kind == FK_INST) {
+        } else if (!PLAIN && kind == FK_INST) {
             m.sp -= 1;
             const uint32_t depth = inst_depth(sc, idx);
             f3 wo, wd, o, d;
             world.ray(wo, wd);
             localize(sc, idx, depth - 1, wo, wd, o, d);  // back to the enclosing space, recomputed from the world ray
             m.set_ray(o, d);
-        } else if (kind == FK_MED1) {
+        } else if (!PLAIN && kind == FK_MED1) {
             if (!m.hitf) {
                 m.tmin = __uint_as_float(stk[(m.sp - 5) * stride]);
                 m.tmax = __uint_as_float(stk[(m.sp - 4) * stride]);
@@ -1016,7 +1019,7 @@ __device__ __forceinline__ void trav_pop(const DevScene& sc, Trav& m, const Worl
                 m.hitf = false;
                 m.node = sc.medium[idx].x;
             }
-        } else {  // FK_MED2
+        } else if (!PLAIN) {  // FK_MED2
             const bool found = m.hitf;
             float t2 = m.tmax;
             float t1 = __uint_as_float(stk[(m.sp - 2) * stride]);

@@ -334,6 +334,7 @@ struct rr_context {
     bool sw_dump_program = false;  // RR_DUMP_PROGRAM: the scene program to stderr at upload
     size_t sw_workspace_cap = 0;   // RR_WF_WORKSPACE_BYTES: cap of the per-batch workspace (0: none), to force many small batches
     bool wide_scene = false;  // the production kernels walk the BVHs with the wide node move (rr_scene_upload says when)
+    bool plain_scene = false;  // no moving spheres, instances or media: k_wf_traverse has a build without their moves
     bool auto_pipeline = false;  // scenes the wavefront pipeline renders unless a flag says otherwise
     bool prog_vector_ops = false;  // the scene program has ops that read records per lane (OP_LEAF_REF, OP_SUBTREE)
     uint32_t root = NONE;
@@ -913,7 +914,7 @@ int render_wavefront(rr_context* ctx, WfArgs a, int count, uint32_t flags, float
     const bool wide = ctx->wide_scene && !(flags & RR_FLAG_NARROW_NODES);  // (a wide scene has the reference's semantics and no general subtrees)
     const TraverseKernel k_traverse = count == COUNT_PRODUCTION ? (wide ? k_wf_traverse<COUNT_PRODUCTION, false, true> : k_wf_traverse<COUNT_PRODUCTION>)
                                       : count == COUNT_REFERENCE ? k_wf_traverse<COUNT_REFERENCE>
-                                      : wide ? k_wf_traverse<COUNT_OFF, true, true>
+                                      : wide ? (ctx->plain_scene ? k_wf_traverse<COUNT_OFF, true, true, true> : k_wf_traverse<COUNT_OFF, true, true>)
                                       : ref_sem ? k_wf_traverse<COUNT_OFF, true> : k_wf_traverse<COUNT_OFF>;
     const FinishKernel k_finish = count == COUNT_PRODUCTION ? k_wf_finish<COUNT_PRODUCTION>
                                   : count == COUNT_REFERENCE ? k_wf_finish<COUNT_REFERENCE>
@@ -1651,6 +1652,7 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     ctx->info.n_prims = s->n_spheres + s->n_moving_spheres + s->n_rects + s->n_triangles;
     ctx->has_triangles = s->n_triangles != 0;
     ctx->wide_scene = wide_scene;
+    ctx->plain_scene = s->n_moving_spheres == 0 && s->n_media == 0 && s->n_instances == 0;
     ctx->info.wide_nodes = wide_scene ? 1u : 0u;
     ctx->lean_scene = all_canonical && wk.max_inst_depth <= 2;
     ctx->has_subtrees = false;

@@ -25,8 +25,13 @@
 // f32 sum is taken in the reference's order, so this form and k_render produce the same bits.
 #pragma once
 
+// Waves per SIMD k_wf_traverse is compiled for: 7, a budget of 72 vector registers.  At 8 (64 registers) the build with the
+// wide node move keeps 64 scalar values in vector lanes and moves them at 511 places; at 7 it is 32 values and 200 places
+// and a sixth fewer vector instructions in the binary (1.1 M-primitive mesh +7.5 %, whose 23-word stacks leave room for 6
+// workgroups per CU either way; the pipeline on Suzanne / final_scene / random spheres, which lose a wave, +3.7 / +3.3 /
+// +9.7 %).  6 and 5: the same code as 7.
 #ifndef RR_WF_TRAVERSE_WAVES_PER_SIMD
-#define RR_WF_TRAVERSE_WAVES_PER_SIMD 8
+#define RR_WF_TRAVERSE_WAVES_PER_SIMD 7
 #endif
 #ifndef RR_WF_SHADE_WAVES_PER_SIMD
 #define RR_WF_SHADE_WAVES_PER_SIMD 3
@@ -447,7 +452,8 @@ struct WfDraw {
 
 // WIDE: every BVH node is walked with the wide node move (trav_node_wide): the host asks for it only when all of them are of a
 // culling class, none has anything but BVH nodes, spheres, rects, triangles and cuboids below, and the semantics are the reference's.
-template <int COUNT, bool REF_SEM = false, bool WIDE = false>  // REF_SEM: as for k_wf_paths
+// PLAIN: the scene has no moving spheres, instances or media (trav_leaf).
+template <int COUNT, bool REF_SEM = false, bool WIDE = false, bool PLAIN = false>  // REF_SEM: as for k_wf_paths
 __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     k_wf_traverse(DevScene sc_arg, WfArgs a, WfState st, const uint32_t* __restrict__ queue, WfCtl* ctl, uint32_t root,
                   unsigned long long* counters) {
@@ -535,10 +541,10 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
         const uint32_t n_leaf = static_cast<uint32_t>(__popcll(RR_BALLOT(at_leaf)));
         const uint32_t n_node = static_cast<uint32_t>(__popcll(RR_BALLOT(active && trav_at_node(m))));
         if (n_leaf != 0 && (n_leaf >= RR_WF_LEAF_LANES || n_leaf >= n_node)) {
-            if (at_leaf) trav_leaf<COUNT>(sc, m, world, stk, stride, cnt);
+            if (at_leaf) trav_leaf<COUNT, WfWorld, PLAIN>(sc, m, world, stk, stride, cnt);
         }
         if (active) {
-            trav_pop<COUNT, WfWorld, WfDraw, WIDE>(sc, m, world, draw, stk, stride, cnt);
+            trav_pop<COUNT, WfWorld, WfDraw, WIDE, PLAIN>(sc, m, world, draw, stk, stride, cnt);
             draws = draw.n;
             if (m.finished()) {
                 // the hit's material and owner are fetched here, where the latency hides behind other rays' work
