@@ -270,7 +270,7 @@ typedef struct rr_render_params {
 /* The library renders with one of three kernel organisations that produce the same bits.  The default is a
  * persistent kernel whose lanes follow single paths from camera ray to termination and leave the sample
  * values for an in-order accumulation.  Scenes that are all BVH (fewer than four things outside the BVH
- * subtrees) and larger than 1 MiB go through a wavefront pipeline instead: traversal and shading kernels over a compacted queue of
+ * subtrees) with more than 2 MiB of BVH and primitive records go through a wavefront pipeline instead: traversal and shading kernels over a compacted queue of
  * live paths for the camera rays, then a persistent kernel for the rest of every path; RR_FLAG_WAVEFRONT
  * forces that pipeline for any scene.  RR_FLAG_PERSISTENT selects the third, a persistent kernel whose
  * lanes own a (slice, pixel) at a time and add its samples themselves.                                  */
@@ -337,7 +337,7 @@ typedef struct rr_scene_info {
     uint32_t max_inst_depth; /* deepest instance nesting                 */
     uint64_t device_bytes;   /* bytes of scene data resident in HBM      */
     uint32_t n_prims;        /* spheres + moving spheres + rects + triangles */
-    uint32_t wavefront;      /* 1: rendered by the wavefront pipeline unless a flag says otherwise (nearly all of the scene is inside BVHs, and it is larger than 1 MiB) */
+    uint32_t wavefront;      /* 1: rendered by the wavefront pipeline unless a flag says otherwise (nearly all of the scene is inside BVHs, and its BVH and primitive records exceed 2 MiB) */
     uint32_t bvh_nodes_by_class[4]; /* how the production kernels treat the BVH nodes: [0] no box, [1] exactly as the
                                        reference (a constant medium below, or a box that does not hold what is below),
                                        [2] redundant visits skipped and subtrees culled against [t_min,t_max],

@@ -1679,9 +1679,13 @@ int rr_scene_upload(rr_context* ctx, const rr_flat_scene* s) {
     // (Since the path kernel stopped spilling and went to 5 waves it is also ahead on small all-BVH scenes: random spheres 4630
     // against 3965 Msamples/s at 1000 spp.  The pipeline keeps the larger ones, whose traversal waits for memory: measured on
     // height fields with spheres of 0.5 / 2 / 5.6 / 20 / 48 / 95 MB (1280x720, 16 spp), path kernel against pipeline: 8.1 / 8.1,
-    // 19.9 / 16.5, 54.6 / 40.8, 156 / 100, 358 / 210 ms, and 31.2 against 40.9 Msamples/s on the 1.1 M-primitive mesh.)
-    // (the threshold is about where the BVHs and primitives stop being cache-resident: textures and tables do not count)
-    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && geometry_bytes > (1u << 20);
+    // 19.9 / 16.5, 54.6 / 40.8, 156 / 100, 358 / 210 ms, and 31.2 against 40.9 Msamples/s on the 1.1 M-primitive mesh.
+    // Measured again after the path kernel ended dead paths and took its pixels in tiles and the pipeline's traversal went
+    // cohort by cohort (profiles/crossover.py; 0.57 / 2.3 / 5.8 / 20 / 56 / 111 MB on the device, of which the records counted
+    // here are 0.25 / 1.0 / 2.8 / 10 / 26 / 51 MB): 5.4 / 8.6, 9.6 / 14.0, 25.2 / 18.8, 61.9 / 27.7, 172 / 63, 371 / 127 ms.)
+    // (the threshold is about where the BVHs and primitives stop being cache-resident — with the records of the wide node move,
+    // which double the nodes, one die's L2 of 4 MB: textures and tables do not count)
+    ctx->auto_pipeline = ctx->has_subtrees && top_ops < 4 && geometry_bytes > (2u << 20);
     if (ctx->has_subtrees && lds_bytes + 4u * PARK_LDS_WORDS_PER_WAVE * 4u > static_cast<size_t>(ctx->max_dynamic_lds)) {
         ctx->scene_mem.release();
         return fail(RR_E_LIMIT, "rr_scene_upload: traversal stacks of " + std::to_string(stack_words) + " words per lane (" + std::to_string(lds_bytes) +

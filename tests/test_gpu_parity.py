@@ -142,7 +142,7 @@ def test_bvh_whose_root_box_does_not_hold_the_boxes_below(gpu_ctx, name):
 
 
 def test_which_scenes_take_the_wavefront_pipeline(gpu_ctx):
-    """rr_scene_info.wavefront: scenes that are all BVH and larger than 1 MiB go through the wavefront pipeline by default, every
+    """rr_scene_info.wavefront: scenes that are all BVH with more than 2 MiB of BVH and primitive records go through the wavefront pipeline by default, every
     other scene through the path kernel; whichever runs, the bits are the other's."""
     for name, kw, want in [("spheres", {}, False), ("final", {}, False), ("suzanne", {}, False),
                            ("mesh", dict(n_triangles=60_000, n_spheres=6_000), True)]:
