@@ -154,7 +154,7 @@ __device__ __forceinline__ WfPathPos wf_path_pos(const WfArgs& a, uint32_t p) {
     const uint32_t strip = p / per_strip, rem = p - strip * per_strip;
     const uint32_t first = strip * a.strip_pixels;
     const uint32_t len = min(a.strip_pixels, a.n_pixels - first);  // (the last strip may be shorter)
-    if (len == RR_WF_STRIP_ROWS * a.width) {  // a full strip: its pixels go cell by cell (wf_strip_pos_to_pix)
+    if (len == RR_WF_STRIP_ROWS * a.width) {  // a full strip: its paths go cell by cell
         const WfPathPos q = wf_strip_pos(a, rem);
         return WfPathPos{first + q.pix, q.sub};
     }
