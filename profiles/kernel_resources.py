@@ -12,11 +12,14 @@ sys.path.insert(0, ROOT)
 import rust_raytracer_amd  # noqa: E402,F401
 from rust_raytracer_amd import build  # noqa: E402
 
-src = os.path.join(build.CSRC, "rr_hip.hip")
-r = subprocess.run(["/opt/rocm/bin/hipcc"] + build.HIPCC_FLAGS + ["-I", build.CSRC, "-I", build.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/rr_resources.so", src],
-                   capture_output=True, text=True)
+remarks = ""
+for unit, extra in (("rr_hip.hip", []), ("rr_paths_minreg.hip", build.MINREG_FLAGS)):  # the library's two translation units
+    r = subprocess.run(["/opt/rocm/bin/hipcc"] + [f for f in build.HIPCC_FLAGS if f != "-shared"] + extra +
+                       ["-I", build.CSRC, "-I", build.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/tmp/rr_resources.o",
+                        os.path.join(build.CSRC, unit)], capture_output=True, text=True)
+    remarks += r.stderr
 want = sys.argv[1:] or ["k_wf_paths", "k_wf_traverse", "k_wf_finish", "k_render", "k_wf_shade"]
-for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
+for b in re.split(r"remark: [^\n]*Function Name: ", remarks)[1:]:
     name = b.split("\n")[0].split()[0].strip()
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r"\(.*", "", dem).replace("void ", "")

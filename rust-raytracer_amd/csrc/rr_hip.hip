@@ -272,6 +272,10 @@ __global__ void __launch_bounds__(256) k_add_images(float* __restrict__ dst, con
 
 #include "rr_wavefront.h"
 
+// The builds of k_wf_paths that rr_paths_minreg.hip holds (compiled with another instruction scheduler): the host-side handle of
+// the one for scenes with one simple subtree under the reference's semantics.
+__attribute__((visibility("hidden"))) void (*rr_paths_kernel_one_subtree(bool lean))(DevScene, WfArgs, float4*, unsigned int*, unsigned long long*);
+
 // Device memory of rr_render_device_noalloc, the entry point that allocates nothing: the counter its waves claim paths
 // from (first 256 bytes) and the sample values of the paths in flight (16 bytes each).  One copy per GPU, held until
 // the process ends.  Host code reaches it only through the address hipGetSymbolAddress returns for the current device
@@ -1036,7 +1040,9 @@ PathsChoice choose_paths_kernel(const rr_context* ctx, int count) {
         // (two or more subtrees: the builds in which parked lanes are guests of the other subtrees' visits)
         if (ctx->info.subtree_ops[0] >= 2u)
             return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false, true);
-        return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false);
+        // (one subtree: the same builds, compiled in rr_paths_minreg.hip with the scheduler that minimises register use)
+        return w5 ? PathsChoice{rr_paths_kernel_one_subtree(true), "COUNT_OFF, true, true, false, true, W5, true"}
+                  : PathsChoice{rr_paths_kernel_one_subtree(false), "COUNT_OFF, true, true, false, true, W5, false"};
     }
     if (ctx->prog_vector_ops) {
         // (without subtrees REF_SEM only concerns shading: the builds that know the book estimator is off do not carry its code)

@@ -216,6 +216,9 @@ __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_
     sample = a.sample_offset + (a.slice_first + q.sub % a.pass_slices) * a.spt + a.s0 + q.sub / a.pass_slices;
 }
 
+// (RR_WF_TEMPLATES_ONLY: a second translation unit of the library includes this file for builds of the kernel templates and
+// leaves the kernels that are no templates to the first.)
+#ifndef RR_WF_TEMPLATES_ONLY
 // render.rs:95-98: every path of the batch starts at its camera ray with throughput one and full depth.
 __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState st, uint32_t* __restrict__ queue, WfCtl* ctl,
                                                  unsigned long long* counters) {
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
     }
     dst[0] = acc.x, dst[1] = acc.y, dst[2] = acc.z;
 }
+#endif  // RR_WF_TEMPLATES_ONLY
 
 #ifndef RR_WF_FINISH_PARK_BELOW
 #define RR_WF_FINISH_PARK_BELOW 20  // k_wf_finish: lanes still descending in a subtree are parked once fewer than this many are left
@@ -558,6 +562,7 @@ __global__ void __launch_bounds__(256, RR_WF_TRAVERSE_WAVES_PER_SIMD)
     flush_counts(cnt, counters);
 }
 
+#ifndef RR_WF_TEMPLATES_ONLY
 __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(DevScene sc, WfArgs a, WfState st, const uint32_t* __restrict__ queue_in,
                                                   const WfCtl* ctl_in, uint32_t* __restrict__ queue_out, WfCtl* ctl_out, WfCtl* ctl_clear,
                                                   unsigned long long* counters) {
@@ -670,6 +675,7 @@ __global__ void __launch_bounds__(256, RR_WF_SHADE_WAVES_PER_SIMD) k_wf_shade(De
     }
     flush_counts(cnt, counters);
 }
+#endif  // RR_WF_TEMPLATES_ONLY
 
 #ifndef RR_WF_FINISH_WAVES_PER_SIMD
 #define RR_WF_FINISH_WAVES_PER_SIMD 4
