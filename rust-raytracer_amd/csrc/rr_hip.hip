@@ -1914,8 +1914,10 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.pass_slices = here;
             w.strip_pixels = 0;
-            // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix)
+            // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix; with two
+            // or more subtrees, all samples of a 2x2 cell of pixels together: wf_path_key)
             w.tile_paths = (!wavefront && ctx->has_subtrees && !(p->flags & RR_FLAG_ROW_ORDER)) ? 1u : 0u;
+            if (w.tile_paths && ctx->info.subtree_ops[0] + ctx->info.subtree_ops[1] >= 2u) w.tile_paths = 2u;
             if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
                 w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
             w.claim_max = ctx->auto_pipeline ? RR_WF_CLAIM_LARGE_SCENE : RR_WF_CLAIM_SMALL_SCENE;
