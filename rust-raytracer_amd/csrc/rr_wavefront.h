@@ -280,11 +280,25 @@ __global__ void __launch_bounds__(256) k_wf_init(DevScene sc, WfArgs a, WfState 
 
 // pixel_color of render.rs:93-100 for one slot: the batch's sample values added in sample order.
 __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, float* __restrict__ slice_sums) {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.n_slots) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_slots) return;
+    uint32_t pix = t % a.n_pixels, slice = t / a.n_pixels;
+    if (a.strip_pixels == 0u && a.tile_paths == 2u) {
+        // Paths numbered cell by cell (wf_path_key): neighbouring threads take the (slice, pixel) pairs whose values are
+        // neighbours in memory — a cell's four pixels, slice by slice — so that a wave reads whole lines in every turn of the
+        // loop below (with a thread per pixel of a row it read 16 bytes of every 64: 66 instead of 17 ms on final_scene).
+        const uint32_t tiled = (a.width & ~7u) * ((a.n_pixels / a.width) & ~7u), cell_threads = tiled * a.pass_slices;
+        if (t < cell_threads) {
+            const uint32_t per_cell = 4u * a.pass_slices, c = t / per_cell, r = t - c * per_cell;
+            slice = r >> 2, pix = wf_tile_to_pix(a, c * 4u + (r & 3u));
+        } else {
+            const uint32_t u = t - cell_threads, rest = a.n_pixels - tiled;
+            slice = u / rest, pix = wf_tile_to_pix(a, tiled + (u - slice * rest));
+        }
+    }
+    const uint32_t slot = slice * a.n_pixels + pix;
     float* dst = slice_sums + (static_cast<uint64_t>(a.slice_out) * a.n_pixels + slot) * 3u;
     f3 acc = a.s0 == 0 ? mk3(0.f, 0.f, 0.f) : mk3(dst[0], dst[1], dst[2]);
-    const uint32_t pix = slot % a.n_pixels, slice = slot / a.n_pixels;
     for (uint32_t sub = slice; sub < a.n_sub; sub += a.pass_slices) {  // this slot's samples of the batch, in sample order
         const float4 c = st.thr[wf_path_index(a, pix, sub)];
         acc = acc + mk3(c.x, c.y, c.z);
