@@ -1022,6 +1022,7 @@ using PathsKernel = void (*)(DevScene, WfArgs, float4*, unsigned int*, unsigned 
 struct PathsChoice {
     PathsKernel fn;
     const char* targs;
+    bool cells = false;  // a build that can take its paths cell by cell (WfArgs::tile_paths == 2): the guests builds
 };
 constexpr int W5 = RR_RENDER_WAVES_PER_SIMD + 1;
 #define RR_PK(...) PathsChoice{k_wf_paths<__VA_ARGS__>, #__VA_ARGS__}
@@ -1038,8 +1039,11 @@ PathsChoice choose_paths_kernel(const rr_context* ctx, int count) {
         // (scenes whose subtrees are all simple take 5 waves whether lean or not: Suzanne +4 % once parked lanes stopped
         // holding two copies of their ray; a lean build for lean scenes with triangles measured no different from the full one)
         // (two or more subtrees: the builds in which parked lanes are guests of the other subtrees' visits)
-        if (ctx->info.subtree_ops[0] >= 2u)
-            return w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false, true);
+        if (ctx->info.subtree_ops[0] >= 2u) {
+            PathsChoice c = w5 ? RR_PK(COUNT_OFF, true, true, false, true, W5, true, true) : RR_PK(COUNT_OFF, true, true, false, true, W5, false, true);
+            c.cells = true;
+            return c;
+        }
         // (one subtree: the same builds, compiled in rr_paths_minreg.hip with the scheduler that minimises register use)
         return w5 ? PathsChoice{rr_paths_kernel_one_subtree(true), "COUNT_OFF, true, true, false, true, W5, true"}
                   : PathsChoice{rr_paths_kernel_one_subtree(false), "COUNT_OFF, true, true, false, true, W5, false"};
@@ -1068,6 +1072,7 @@ int render_paths_in(rr_context* ctx, WfArgs a, int count, float* sums, unsigned 
     st.thr = values;
     const PathsChoice choice = choose_paths_kernel(ctx, count);
     const PathsKernel kernel = choice.fn;
+    if (a.tile_paths == 1u && choice.cells) a.tile_paths = 2u;  // cell by cell: wf_path_key
     // the kernel rr_scene_specialize compiled for this scene's program stands in for the interpreter's build of the same name
     const bool jit = count == COUNT_OFF && ctx->jit_fn != nullptr && ctx->jit_targs == choice.targs;
     // the stacks, then (scenes with subtrees) each wave's slots for parked lanes
@@ -1914,10 +1919,9 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
             w.n_slots = static_cast<uint32_t>(here * n_pixels);
             w.pass_slices = here;
             w.strip_pixels = 0;
-            // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix; with two
-            // or more subtrees, all samples of a 2x2 cell of pixels together: wf_path_key)
+            // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix; the builds
+            // for two or more simple subtrees, all samples of a 2x2 cell of pixels together: render_paths_in)
             w.tile_paths = (!wavefront && ctx->has_subtrees && !(p->flags & RR_FLAG_ROW_ORDER)) ? 1u : 0u;
-            if (w.tile_paths && ctx->info.subtree_ops[0] + ctx->info.subtree_ops[1] >= 2u) w.tile_paths = 2u;
             if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
                 w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
             w.claim_max = ctx->auto_pipeline ? RR_WF_CLAIM_LARGE_SCENE : RR_WF_CLAIM_SMALL_SCENE;

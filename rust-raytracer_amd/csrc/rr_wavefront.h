@@ -212,15 +212,17 @@ __device__ __forceinline__ uint32_t wf_pix_to_tile(const WfArgs& a, uint32_t pix
     if (y < r8) return w8 * r8 + y * (a.width - w8) + (x - w8);
     return r8 * a.width + (pix - r8 * a.width);  // (= pix: everything above is counted, in whatever order)
 }
-template <bool STRIPS = true>
+// CELLS = false: a build that knows the numbering is not cell by cell (tile_paths != 2).
+template <bool STRIPS = true, bool CELLS = true>
 __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_t& pixel, uint32_t& sample) {
-    if (!STRIPS && a.tile_paths == 2u) {
-        // Cell by cell (the path kernel on scenes with two or more BVH subtrees): all of the batch's paths of a 2x2 cell of pixels,
+    if (!STRIPS && CELLS && a.tile_paths == 2u) {
+        // Cell by cell (the builds of the path kernel for scenes with two or more simple BVH subtrees: GUESTS): all of the batch's paths of a 2x2 cell of pixels,
         // every slice and sample, before the next cell's, the cells in the order of wf_tile_to_pix; then the pixels no 8x8 tile
         // covers, sample-major.  A wave's 64 camera rays are then 16 samples of four neighbouring pixels, and the waves of the
         // chip work on one region of the image at a time.  Measured against 8x8 tiles of one sample each: final_scene at 8 / 64 /
         // 400 / 2 000 / 10 000 samples per pixel +2.6 / +24 / +5.6 / +2.9 / +2.0 %; scenes with one subtree: random spheres at 1000
-        // samples +6.2 %, at 100 samples -7.0 %, Suzanne -1.1 %, which is why they keep the tiles.
+        // samples +6.2 %, at 100 samples -7.0 %, Suzanne -1.1 %, which is why they keep the tiles (and their builds do not carry
+        // this code: with it Suzanne's build came out 2.3 % slower).
         const uint32_t tiled = (a.width & ~7u) * ((a.n_pixels / a.width) & ~7u), cell_part = tiled * a.n_sub;
         uint32_t q, sub;
         if (p < cell_part) {
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(256, WAVES) k_wf_paths(DevScene sc_arg, WfArgs
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
             if (!path_active && rank < take) {
                 p = chunk_pos + rank;
-                wf_path_key<false>(a, p, pixel, sample);
+                wf_path_key<false, GUESTS>(a, p, pixel, sample);  // (the host asks for cells in the guests builds only)
                 Rng g;
                 g.start(a.seed, pixel, sample, CAMERA_BOUNCE);
                 camera_ray(sc, a.width, a.height, pixel % a.width, a.height - 1u - pixel / a.width, g, ro, rd, time);
