@@ -109,6 +109,14 @@ struct WfArgs {
 // that is what lets each die keep its part of the scene in its own L2 (k_wf_traverse).  The numbering changes no result:
 // every random stream is keyed by (pixel, sample), and k_wf_accumulate adds a pixel's samples in sample order either way.
 // STRIPS = false: a build that knows the numbering is sample-major.
+// The cells of the path kernel's cell-by-cell numbering (WfArgs::tile_paths == 2, wf_path_key): 2^WF_CELL_LOG2 pixels that follow
+// each other in the order of wf_tile_to_pix.  One pixel: a wave's 64 camera rays are 64 samples of it (or all samples of a
+// few neighbours).  Measured on final_scene at 2 000 samples per pixel, against cells of 4 pixels (2x2): 8 pixels -1.0 %,
+// 2 pixels +0.7 %, 1 pixel +1.5 %.
+#ifndef RR_PATHS_CELL_LOG2
+#define RR_PATHS_CELL_LOG2 0
+#endif
+constexpr uint32_t WF_CELL_LOG2 = RR_PATHS_CELL_LOG2;
 struct WfPathPos {
     uint32_t pix;  // pixel within the band of rows
     uint32_t sub;  // s_local * pass_slices + slice_local
@@ -166,7 +174,7 @@ __device__ __forceinline__ uint32_t wf_pix_to_tile(const WfArgs& a, uint32_t pix
 __device__ __forceinline__ uint32_t wf_path_index(const WfArgs& a, uint32_t pix, uint32_t sub) {
     if (a.strip_pixels == 0u && a.tile_paths == 2u) {  // cell by cell: see wf_path_key
         const uint32_t tiled = (a.width & ~7u) * ((a.n_pixels / a.width) & ~7u), q = wf_pix_to_tile(a, pix);
-        if (q < tiled) return (q >> 2) * (4u * a.n_sub) + sub * 4u + (q & 3u);
+        if (q < tiled) return (q >> WF_CELL_LOG2) * ((1u << WF_CELL_LOG2) * a.n_sub) + (sub << WF_CELL_LOG2) + (q & ((1u << WF_CELL_LOG2) - 1u));
         return tiled * a.n_sub + sub * (a.n_pixels - tiled) + (q - tiled);
     }
     if (a.strip_pixels == 0u)
@@ -216,18 +224,18 @@ __device__ __forceinline__ uint32_t wf_pix_to_tile(const WfArgs& a, uint32_t pix
 template <bool STRIPS = true, bool CELLS = true>
 __device__ __forceinline__ void wf_path_key(const WfArgs& a, uint32_t p, uint32_t& pixel, uint32_t& sample) {
     if (!STRIPS && CELLS && a.tile_paths == 2u) {
-        // Cell by cell (the builds of the path kernel for scenes with two or more simple BVH subtrees: GUESTS): all of the batch's paths of a 2x2 cell of pixels,
-        // every slice and sample, before the next cell's, the cells in the order of wf_tile_to_pix; then the pixels no 8x8 tile
-        // covers, sample-major.  A wave's 64 camera rays are then 16 samples of four neighbouring pixels, and the waves of the
-        // chip work on one region of the image at a time.  Measured against 8x8 tiles of one sample each: final_scene at 8 / 64 /
-        // 400 / 2 000 / 10 000 samples per pixel +2.6 / +24 / +5.6 / +2.9 / +2.0 %; scenes with one subtree: random spheres at 1000
+        // Cell by cell (the builds of the path kernel for scenes with two or more simple BVH subtrees: GUESTS): all of the batch's
+        // paths of a cell of pixels (WF_CELL_LOG2), every slice and sample, before the next cell's, the cells in the order of
+        // wf_tile_to_pix; then the pixels no 8x8 tile covers, sample-major.  A wave's 64 camera rays are then samples of one
+        // pixel or of a few neighbours, and the waves of the chip work on one region of the image at a time.  Measured with 2x2 cells
+        // against 8x8 tiles of one sample each: final_scene at 8 / 64 / 400 / 2 000 / 10 000 samples per pixel +2.6 / +24 / +5.6 / +2.9 / +2.0 %; scenes with one subtree: random spheres at 1000
         // samples +6.2 %, at 100 samples -7.0 %, Suzanne -1.1 %, which is why they keep the tiles (and their builds do not carry
         // this code: with it Suzanne's build came out 2.3 % slower).
         const uint32_t tiled = (a.width & ~7u) * ((a.n_pixels / a.width) & ~7u), cell_part = tiled * a.n_sub;
         uint32_t q, sub;
         if (p < cell_part) {
-            const uint32_t per_cell = 4u * a.n_sub, c = p / per_cell, rem = p - c * per_cell;
-            sub = rem >> 2, q = c * 4u + (rem & 3u);
+            const uint32_t per_cell = (1u << WF_CELL_LOG2) * a.n_sub, c = p / per_cell, rem = p - c * per_cell;
+            sub = rem >> WF_CELL_LOG2, q = (c << WF_CELL_LOG2) + (rem & ((1u << WF_CELL_LOG2) - 1u));
         } else {
             const uint32_t r = p - cell_part, rest = a.n_pixels - tiled;
             sub = r / rest, q = tiled + (r - sub * rest);
@@ -287,12 +295,12 @@ __global__ void __launch_bounds__(256) k_wf_accumulate(WfArgs a, WfState st, flo
     uint32_t pix = t % a.n_pixels, slice = t / a.n_pixels;
     if (a.strip_pixels == 0u && a.tile_paths == 2u) {
         // Paths numbered cell by cell (wf_path_key): neighbouring threads take the (slice, pixel) pairs whose values are
-        // neighbours in memory — a cell's four pixels, slice by slice — so that a wave reads whole lines in every turn of the
+        // neighbours in memory — a cell's pixels, slice by slice — so that a wave reads whole lines in every turn of the
         // loop below (with a thread per pixel of a row it read 16 bytes of every 64: 66 instead of 17 ms on final_scene).
         const uint32_t tiled = (a.width & ~7u) * ((a.n_pixels / a.width) & ~7u), cell_threads = tiled * a.pass_slices;
         if (t < cell_threads) {
-            const uint32_t per_cell = 4u * a.pass_slices, c = t / per_cell, r = t - c * per_cell;
-            slice = r >> 2, pix = wf_tile_to_pix(a, c * 4u + (r & 3u));
+            const uint32_t per_cell = (1u << WF_CELL_LOG2) * a.pass_slices, c = t / per_cell, r = t - c * per_cell;
+            slice = r >> WF_CELL_LOG2, pix = wf_tile_to_pix(a, (c << WF_CELL_LOG2) + (r & ((1u << WF_CELL_LOG2) - 1u)));
         } else {
             const uint32_t u = t - cell_threads, rest = a.n_pixels - tiled;
             slice = u / rest, pix = wf_tile_to_pix(a, tiled + (u - slice * rest));
