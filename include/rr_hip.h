@@ -303,7 +303,7 @@ typedef struct rr_render_params {
  * exact: NaN times whatever follows is NaN, which is what the ended path leaves as its sample.                              */
 #define RR_FLAG_TRACE_DEAD_PATHS 128u
 /* The path-granular kernel hands the pixels of a scene with BVH subtrees to its lanes in 8x8 tiles (a wave's camera rays then
- * walk the same part of the BVHs), and with two or more subtrees all samples of a 2x2 cell of pixels together; this flag keeps
+ * walk the same part of the BVHs), and with two or more subtrees all samples of a pixel together; this flag keeps
  * it to 64 pixels of a row per wave, the order it uses for scenes without subtrees (for measurements and tests: the order
  * changes no result).                                                                                                        */
 #define RR_FLAG_ROW_ORDER 256u

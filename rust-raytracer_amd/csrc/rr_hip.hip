@@ -1920,7 +1920,7 @@ int render_device(rr_context* ctx, const rr_render_params* p, void* d_slice_sums
             w.pass_slices = here;
             w.strip_pixels = 0;
             // (the path kernel on scenes with BVH subtrees hands out pixels in 8x8 tiles: rr_wavefront.h, wf_tile_to_pix; the builds
-            // for two or more simple subtrees, all samples of a 2x2 cell of pixels together: render_paths_in)
+            // for two or more simple subtrees, all samples of a pixel together: render_paths_in)
             w.tile_paths = (!wavefront && ctx->has_subtrees && !(p->flags & RR_FLAG_ROW_ORDER)) ? 1u : 0u;
             if (wavefront && RR_WF_STRIP_ROWS != 0u)  // (the pipeline numbers its paths strip by strip: rr_wavefront.h, wf_path_key)
                 w.strip_pixels = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(p->width) * RR_WF_STRIP_ROWS, n_pixels));
